@@ -1,0 +1,73 @@
+"""CPU ORACLE (test infrastructure) — `VideoCompressor` of `main/model/pnet.py:15-83`.
+
+fp32 CPU restatement of the per-P-frame encode + reconstruct path; the autocast regions of
+the reference are no-ops on CPU, the one reduced-precision quirk that survives is the
+DCN's unconditional fp16 output (see blocks.DCN).  State-dict keys match the reference
+(`mvCoder, resCoder, extra_fea, motion_est, mcnet, loopfilter, mcfilter`).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from .blocks import FeaExtra, FeatureFix, LoopFilter, MCNet, OffsetGen
+from .coder import MVCoder, ResCoder
+
+
+def bpp_from_likelihoods(liks, num_pixels):
+    """`main/model/pnet.py:38-43`."""
+    return sum(torch.log(l).sum() / (-math.log(2) * num_pixels) for l in liks.values())
+
+
+class VideoCompressor(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.mvCoder = MVCoder(N=128)
+        self.resCoder = ResCoder(N=128)
+        self.extra_fea = FeaExtra(2)
+        self.motion_est = OffsetGen()
+        self.mcnet = MCNet(3)
+        self.loopfilter = FeatureFix()      # in-loop filter (sic, `pnet.py:23`)
+        self.mcfilter = LoopFilter()        # multi-frame fusion (sic, `pnet.py:24`)
+
+    def forward(self, input_image, refer_frames, enabled_amp=False, is_compress=False, trace=None):
+        ref = refer_frames[:, -1].clone()
+        f_cur = self.extra_fea(input_image)
+        f_ref = self.extra_fea(ref)
+        estmv = self.motion_est(f_cur, f_ref, input_image, ref)
+
+        mv = self.mvCoder(estmv.float())
+        mv_aux = self.mvCoder.aux_loss()
+        N, _, H, W = input_image.shape
+        npx = N * H * W
+        bpp_mv = bpp_from_likelihoods(mv["likelihoods"], npx)
+        strings = {}
+        if is_compress:
+            self.mvCoder.eval()
+            self.mvCoder.update(force=True)
+            strings["mv"] = self.mvCoder.compress(estmv.float())
+
+        pred1 = self.mcnet(mv["x_hat"], f_ref)
+        pred = self.mcfilter(pred1, refer_frames)
+        resid = f_cur - pred
+
+        rs = self.resCoder(resid.float())
+        res_aux = self.resCoder.aux_loss()
+        bpp_res = bpp_from_likelihoods(rs["likelihoods"], npx)
+        if is_compress:
+            self.resCoder.eval()
+            self.resCoder.update(force=True)
+            strings["res"] = self.resCoder.compress(resid.float())
+
+        recon_f = pred + rs["x_hat"]
+        recon = self.loopfilter(recon_f, refer_frames).clamp(0.0, 1.0)
+
+        if trace is not None:
+            trace.update(f_cur=f_cur, f_ref=f_ref, estmv=estmv, mv_x_hat=mv["x_hat"], pred1=pred1, pred=pred,
+                         resid=resid, res_x_hat=rs["x_hat"], recon_f=recon_f, recon=recon,
+                         mv_dbg=mv["_debug"], res_dbg=rs["_debug"], strings=strings)
+        if self.training:
+            return recon, bpp_res.view(-1), bpp_mv.view(-1), mv_aux, res_aux
+        return recon, bpp_res.view(-1), bpp_mv.view(-1)
