@@ -1,0 +1,221 @@
+/*
+ * tdvc_hip.h — C-ABI of libtdvc_hip.so: MI355X (gfx950) kernels for TDVC's per-P-frame
+ * encode / reconstruct hot path (`main/model/pnet.py::VideoCompressor.forward`).
+ *
+ * Boundary rules
+ *   - plain pointers, sizes and a `void* stream` (a hipStream_t; NULL = default stream);
+ *     no torch types.  All device pointers must be 16-byte aligned.
+ *   - every entry point ENQUEUES on `stream` and returns immediately (no host sync, no
+ *     allocation, graph-capture safe) — the contract of the reference's only FFI crossing,
+ *     `_ext.dcn_v2_forward`, which enqueues on the current CUDA stream
+ *     (main/utils/dcnv2/src/cuda/dcn_v2_cuda.cu:78).
+ *   - return value: 0 on success, a negative TDVC_E* code on invalid arguments, or the
+ *     positive hipError_t of a failed launch.  (The reference only printf's launch failures,
+ *     src/cuda/dcn_v2_im2col_cuda.cu:346-350; here they are returned.)
+ *
+ * Feature maps ("fmap") are channel-innermost: element (n, y, x, c) lives at
+ *     base + n*sn + (y*W + x)*sp + c            (strides in ELEMENTS)
+ * so a tensor may be a channel slice of a wider buffer (concatenation without copies).
+ * fp16 fmaps need C, sp and the channel offset to be multiples of 8.
+ *
+ * Which reference function each entry replaces is stated per declaration (file:line under
+ * /root/reference).
+ */
+#ifndef TDVC_HIP_H
+#define TDVC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDVC_OK 0
+#define TDVC_EINVAL (-1)   /* bad shape / alignment / unsupported configuration */
+#define TDVC_ENOSUP (-2)
+
+/* ---------------------------------------------------------------- descriptors */
+typedef struct {
+  void* p;      /* device pointer to element (0,0,0,0) of the view */
+  int32_t N, H, W, C;
+  int64_t sn;   /* batch stride (elements) */
+  int32_t sp;   /* pixel stride (elements) */
+  int32_t dtype; /* TDVC_F16 or TDVC_F32 */
+} tdvc_fmap;
+
+enum { TDVC_F16 = 0, TDVC_F32 = 1 };
+enum { TDVC_ACT_NONE = 0, TDVC_ACT_RELU = 1, TDVC_ACT_LRELU = 2, TDVC_ACT_CLAMP01 = 3, TDVC_ACT_SIGMOID = 4 };
+enum { TDVC_GDN_NONE = 0, TDVC_GDN_FWD = 1, TDVC_GDN_INV = 2 };
+enum { TDVC_OUT_NHWC = 0,       /* y is an fmap (fp16 or fp32) */
+       TDVC_OUT_SHUFFLE2 = 1,   /* PixelShuffle(2): out channel o -> (c=o/4, i=(o/2)&1, j=o&1), y has 2H x 2W */
+       TDVC_OUT_NCHW_F32 = 2 }; /* planar fp32 [N][C][H][W] (module boundary) */
+
+#define TDVC_MAX_TAPS 49
+
+typedef struct {
+  tdvc_fmap x;            /* input, fp16 */
+  tdvc_fmap y;            /* output view (post-shuffle geometry for SHUFFLE2) */
+  const void* w;          /* weights packed by tdvc_pack_conv_weights (fp16, MFMA fragment order) */
+  const float* bias;      /* [cout_pad] fp32, may be NULL */
+  int32_t cout;           /* real output channels */
+  int32_t ntaps;          /* taps actually evaluated (masked taps are dropped at pack time) */
+  int8_t tap_dy[TDVC_MAX_TAPS], tap_dx[TDVC_MAX_TAPS]; /* tap offsets in [0,KH) x [0,KW) */
+  int32_t kh, kw, stride, pad;
+  int32_t ck;             /* channel chunk staged in LDS per pass: 8,16,32 or 64 (from tdvc_conv_plan) */
+  int32_t square_input;   /* 1: stage x^2 (GDN norm pool) */
+  int32_t gdn;            /* TDVC_GDN_*: v = aux * rsqrt(v) (FWD) or aux * sqrt(v) (INV) */
+  tdvc_fmap aux;          /* GDN multiplicand (same geometry as y pre-shuffle), fp16 */
+  int32_t act; float slope;
+  int32_t round_before_act; /* 1: round v to fp16 before the activation (DCN quirk, dcn_v2_amp.py:67-68) */
+  tdvc_fmap res;          /* residual added AFTER the activation, at output coordinates; p==NULL: none */
+  tdvc_fmap res2;         /* optional second residual (fp16), same rules */
+  int32_t out_mode;
+} tdvc_conv_desc;
+
+/* ---------------------------------------------------------------- library */
+/* Library/ABI version; bumps when a struct above changes. */
+int tdvc_abi_version(void);
+/* Human-readable description of the last error on this thread (never NULL). */
+const char* tdvc_last_error(void);
+
+/* ---------------------------------------------------------------- conv transforms
+ * Replaces every torch.nn.Conv2d / Conv3d(1,3,3) / Conv3d(3,1,1) / compressai
+ * conv3x3 / subpel_conv3x3 / MaskedConv2d / GDN 1x1 call on the path:
+ * main/model/pnet.py:93-96,132-166,180-184,213-262,278-292,309-317,327-332;
+ * main/model/flownet.py:187-227; main/model/encoder_v3.py:17-40,46-69;
+ * main/utils/utils.py:52-56; compressai layers (not in tree).                       */
+
+/* Choose the LDS channel chunk for a geometry. Returns ck (8/16/32/64) or <0. */
+int tdvc_conv_plan(int cin, int kh, int kw, int stride);
+/* Size in bytes of the packed weight blob for (cout, cin, ntaps, ck). */
+int64_t tdvc_conv_packed_bytes(int cout, int cin, int ntaps, int ck);
+/* Host-side packing: w_oihw fp32 [cout][cin_real][kh][kw] -> fragment-ordered fp16 (host
+ * memory, caller uploads).  tap list selects/permutes kernel positions; channels
+ * cin_real..cin-1 are zero.  dst is uint16 (IEEE half bits). */
+int tdvc_pack_conv_weights(const float* w_oihw, int cout, int cin_real, int cin, int kh, int kw,
+                           int ntaps, const int8_t* tap_dy, const int8_t* tap_dx, int ck, uint16_t* dst);
+int tdvc_conv2d(const tdvc_conv_desc* d, void* stream);
+
+/* ---------------------------------------------------------------- deformable conv (motion compensation)
+ * Fused modulated deformable 3x3 conv, fp16 NHWC, no column buffer:
+ * replaces DCN.forward's `_DCNv2.apply` (main/utils/dcnv2/dcn_v2_amp.py:219-234) =
+ * dcn_v2_cuda_forward (src/cuda/dcn_v2_cuda.cu:20-95) + modulated_deformable_im2col
+ * (src/cuda/dcn_v2_im2col_cuda.cu:125-195).
+ * om: fp16 fmap with 27*G channels = raw conv_offset_mask output [o1 | o2 | mask_logits]
+ * (sigmoid applied here, dcn_v2_amp.py:220-223). Cin = Cout = 8*G, 8 channels per group. */
+typedef struct {
+  tdvc_fmap x, om, y;
+  const void* w;        /* packed with tdvc_pack_conv_weights(ck = 64, 9 taps row-major) */
+  const float* bias;
+  int32_t groups;
+  int32_t act; float slope; int32_t round_before_act;
+} tdvc_dcn_desc;
+int tdvc_dcn_fused(const tdvc_dcn_desc* d, void* stream);
+
+/* fp32 NCHW operator with the exact signature semantics of `_ext.dcn_v2_forward`
+ * (src/vision.cpp:3-8, src/dcn_v2.h:9-45): contiguous fp32 tensors, output [B][Cout][Ho][Wo]. */
+int tdvc_dcn_v2_forward_f32(const float* input, const float* weight, const float* bias,
+                            const float* offset, const float* mask, float* output,
+                            int B, int C, int H, int W, int Cout,
+                            int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                            int deformable_group, void* stream);
+/* `_ext.dcn_v2_backward` (src/dcn_v2.h:48-92, src/cuda/dcn_v2_cuda.cu:97-216). All grads
+ * are OVERWRITTEN (zero-initialised inside). `columns` is caller-provided scratch of
+ * C*kh*kw*Ho*Wo floats (per-sample column buffer, reused across the batch). */
+int tdvc_dcn_v2_backward_f32(const float* input, const float* weight, const float* bias,
+                             const float* offset, const float* mask, const float* grad_output,
+                             float* grad_input, float* grad_offset, float* grad_mask,
+                             float* grad_weight, float* grad_bias, float* columns,
+                             int B, int C, int H, int W, int Cout,
+                             int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                             int deformable_group, void* stream);
+
+/* ---------------------------------------------------------------- layout / elementwise */
+/* NCHW fp32 [N][C][H][W] -> fmap (fp16 or fp32), channels >= C zero-filled up to y.C. */
+int tdvc_nchw_to_fmap(const float* src, int C, const tdvc_fmap* y, void* stream);
+/* fmap (fp16/fp32) -> NCHW fp32, first C channels. */
+int tdvc_fmap_to_nchw(const tdvc_fmap* x, int C, float* dst, void* stream);
+/* y = act(a * gate[n][c] (optional) ) + r (optional) ; also y2 (optional, other dtype) gets the same value.
+ * gate NULL => no scaling.  Used for SE scaling (main/model/inflate.py:204-208) and plain add/sub. */
+int tdvc_scale_act_res(const tdvc_fmap* a, const float* gate, int act, float slope,
+                       const tdvc_fmap* r, float r_sign, const tdvc_fmap* y, const tdvc_fmap* y2, void* stream);
+/* offset[c] += flow[c & 1] (main/model/pnet.py:163); off fp16 in place, flow fp32 2-channel fmap. */
+int tdvc_add_flow(const tdvc_fmap* off, const tdvc_fmap* flow, void* stream);
+/* x[:, t] = lrelu(x[:, t] + b) for the T channel-slices of width b.C (pnet.py:313-314). */
+int tdvc_bcast_add_act(const tdvc_fmap* x, const tdvc_fmap* b, int T, float slope, void* stream);
+
+/* ---------------------------------------------------------------- SE attention
+ * main/model/inflate.py:159-208.  Deterministic two-stage mean: partial[N][nblocks][C] fp32
+ * scratch, then the gate kernel sums the partials in fixed order, applies the two 1x1 convs
+ * (ReLU, Sigmoid) and writes gate[N][C].  w1: [Cmid][C], w2: [C][Cmid]. */
+int tdvc_channel_sum(const tdvc_fmap* x, float* partial, int nblocks, void* stream);
+int tdvc_se_gate(const float* partial, int nblocks, float inv_count, int N, int C, int Cmid,
+                 const float* w1, const float* b1, const float* w2, const float* b2,
+                 float* gate, void* stream);
+
+/* ---------------------------------------------------------------- resampling
+ * bilinear x2 upsample, align_corners=False (nn.Upsample, main/model/pnet.py:117). fp16 fmaps. */
+int tdvc_upsample2x(const tdvc_fmap* x, const tdvc_fmap* y, void* stream);
+/* 2x2 average pooling, fp32 fmap -> fp32 fmap (F.avg_pool2d, main/model/flownet.py:103-114). */
+int tdvc_avgpool2(const tdvc_fmap* x, const tdvc_fmap* y, void* stream);
+/* One SPyNet level's input assembly — the "bilinear warp" of the path
+ * (main/model/flownet.py:119-138 + flow_warp :8-48):
+ *   flow_up = 2 * bilinear_x2(flow_lo, align_corners=True)   (zeros if flow_lo == NULL)
+ *   warped  = grid_sample(supp, grid + flow_up, bilinear, border, align_corners=True)
+ *   cat8    = [ref(3) | warped(3) | flow_up(2)] as fp16; flow_up is also kept in fp32.
+ * ref/supp: fp32 fmaps with C>=3; flow_lo/flow_up: fp32 2-channel fmaps; cat8: fp16 C=8. */
+int tdvc_spynet_level_input(const tdvc_fmap* ref, const tdvc_fmap* supp, const tdvc_fmap* flow_lo,
+                            const tdvc_fmap* flow_up, const tdvc_fmap* cat8, void* stream);
+/* generic bilinear resize, align_corners=False, fp32 fmaps, optional per-channel scale of the
+ * output (flow rescale, flownet.py:153-173). */
+int tdvc_resize_bilinear(const tdvc_fmap* x, const tdvc_fmap* y, const float* chscale, void* stream);
+
+/* ---------------------------------------------------------------- in-loop filter matching
+ * FeatureFix.forward, main/model/pnet.py:219-255. */
+/* scale x scale average pooling (floor), fp16 fmap -> fp32 [N][hp][wp][C] (nn.AvgPool2d, :224-225) */
+int tdvc_avgpool_k(const tdvc_fmap* x, int scale, float* pooled, int hp, int wp, void* stream);
+/* 3x3 / stride-3 / pad-3 patches of both pooled maps, L2-normalise, cosine similarity, first
+ * -index argmax over reference patches -> idx[N][L] int32, L = ((hp+3)/3+1)*((wp+3)/3+1)
+ * (F.unfold + normalize + bmm + max, :230-236). */
+int tdvc_patch_match(const float* pin, const float* pref, int N, int hp, int wp, int C,
+                     int32_t* idx, void* stream);
+/* gather full-resolution reference blocks by idx (unfold/gather/fold with kernel 3*scale,
+ * :247-254), per-pixel cosine similarity with fin over channels (:255), write
+ * cat = [fin*cor | out*cor] (fp16, 128 channels) (:257). */
+int tdvc_match_gather(const tdvc_fmap* fin, const tdvc_fmap* fref, const int32_t* idx, int scale,
+                      int hp, int wp, const tdvc_fmap* cat, void* stream);
+
+/* ---------------------------------------------------------------- entropy model (rate terms)
+ * compressai EntropyBottleneck.forward, called from main/model/pnet.py:34,58:
+ *   z_hat = round(z - median) + median (eval)  |  z + noise (train, noise != NULL)
+ *   lik   = |sigmoid(s*upper) - sigmoid(s*lower)|, logits chain over filters (3,3,3,3), >= 1e-9
+ * z: fp32 fmap; params: [C][59] floats = softplus(matrix0..4) (33), bias0..4 (13),
+ * tanh(factor0..3) (12), median (1); z_hat: fp16 or fp32 fmap.
+ * *bits_out = sum(-log2 lik) as a double, by a deterministic two-stage reduction through
+ * partial[partial_cap] (needs >= ceil(numel/256) floats). */
+int tdvc_eb_forward(const tdvc_fmap* z, const float* params, const tdvc_fmap* noise,
+                    const tdvc_fmap* z_hat, double* bits_out, float* partial, int partial_cap, void* stream);
+/* compressai GaussianConditional likelihood:
+ *   v   = |round(y - mean)| (eval) | |y + noise - mean| (train)
+ *   lik = Phi((0.5-v)/s) - Phi((-0.5-v)/s), s = max(scale, 0.11), lik >= 1e-9
+ * gp: fp32 fmap with 2C channels [scales | means]. */
+int tdvc_gc_forward(const tdvc_fmap* y, const tdvc_fmap* gp, const tdvc_fmap* noise,
+                    double* bits_out, float* partial, int partial_cap, void* stream);
+/* y_hat = round(y) (half-to-even, torch.round) or y + noise. */
+int tdvc_quantize(const tdvc_fmap* y, const tdvc_fmap* noise, const tdvc_fmap* y_hat, void* stream);
+
+/* ---------------------------------------------------------------- range coder (host side)
+ * compressai `ans` extension (rans64, 16-bit precision, 4-bit bypass) used by
+ * Cheng2020Anchor.compress (main/model/pnet.py:46-49,70-73).  Pure host code, like the
+ * reference's.  Returns number of bytes written to `out` (<= cap) or <0. */
+int64_t tdvc_rans_encode(const int32_t* symbols, const int32_t* indexes, int64_t n,
+                         const int32_t* cdfs, int32_t cdf_stride, const int32_t* cdf_sizes,
+                         const int32_t* offsets, uint8_t* out, int64_t cap);
+int tdvc_rans_decode(const uint8_t* data, int64_t nbytes, const int32_t* indexes, int64_t n,
+                     const int32_t* cdfs, int32_t cdf_stride, const int32_t* cdf_sizes,
+                     const int32_t* offsets, int32_t* symbols_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDVC_HIP_H */

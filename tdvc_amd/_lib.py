@@ -1,0 +1,104 @@
+"""ctypes binding of libtdvc_hip.so (C-ABI declared in include/tdvc_hip.h).
+
+The product path FAILS LOUDLY when the library is missing: there is no CPU or eager-PyTorch
+fallback anywhere in `tdvc_amd`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtdvc_hip.so")
+
+MAX_TAPS = 49
+F16, F32 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_CLAMP01, ACT_SIGMOID = 0, 1, 2, 3, 4
+GDN_NONE, GDN_FWD, GDN_INV = 0, 1, 2
+OUT_NHWC, OUT_SHUFFLE2, OUT_NCHW_F32 = 0, 1, 2
+
+
+class FMapDesc(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("sn", C.c_int64), ("sp", C.c_int32), ("dtype", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("x", FMapDesc), ("y", FMapDesc), ("w", C.c_void_p), ("bias", C.c_void_p),
+                ("cout", C.c_int32), ("ntaps", C.c_int32),
+                ("tap_dy", C.c_int8 * MAX_TAPS), ("tap_dx", C.c_int8 * MAX_TAPS),
+                ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+                ("ck", C.c_int32), ("square_input", C.c_int32), ("gdn", C.c_int32),
+                ("aux", FMapDesc), ("act", C.c_int32), ("slope", C.c_float),
+                ("round_before_act", C.c_int32), ("res", FMapDesc), ("res2", FMapDesc), ("out_mode", C.c_int32)]
+
+
+class DcnDesc(C.Structure):
+    _fields_ = [("x", FMapDesc), ("om", FMapDesc), ("y", FMapDesc), ("w", C.c_void_p), ("bias", C.c_void_p),
+                ("groups", C.c_int32), ("act", C.c_int32), ("slope", C.c_float), ("round_before_act", C.c_int32)]
+
+
+_P = C.c_void_p
+_FM = C.POINTER(FMapDesc)
+_i, _f, _i64 = C.c_int, C.c_float, C.c_int64
+
+# name -> (restype, argtypes); every symbol declared in include/tdvc_hip.h
+SIGNATURES = {
+    "tdvc_abi_version": (_i, []),
+    "tdvc_last_error": (C.c_char_p, []),
+    "tdvc_conv_plan": (_i, [_i, _i, _i, _i]),
+    "tdvc_conv_packed_bytes": (_i64, [_i, _i, _i, _i]),
+    "tdvc_pack_conv_weights": (_i, [_P, _i, _i, _i, _i, _i, _i, _P, _P, _i, _P]),
+    "tdvc_conv2d": (_i, [C.POINTER(ConvDesc), _P]),
+    "tdvc_dcn_fused": (_i, [C.POINTER(DcnDesc), _P]),
+    "tdvc_dcn_v2_forward_f32": (_i, [_P] * 6 + [_i] * 14 + [_P]),
+    "tdvc_dcn_v2_backward_f32": (_i, [_P] * 12 + [_i] * 14 + [_P]),
+    "tdvc_nchw_to_fmap": (_i, [_P, _i, _FM, _P]),
+    "tdvc_fmap_to_nchw": (_i, [_FM, _i, _P, _P]),
+    "tdvc_scale_act_res": (_i, [_FM, _P, _i, _f, _FM, _f, _FM, _FM, _P]),
+    "tdvc_add_flow": (_i, [_FM, _FM, _P]),
+    "tdvc_bcast_add_act": (_i, [_FM, _FM, _i, _f, _P]),
+    "tdvc_channel_sum": (_i, [_FM, _P, _i, _P]),
+    "tdvc_se_gate": (_i, [_P, _i, _f, _i, _i, _i, _P, _P, _P, _P, _P, _P]),
+    "tdvc_upsample2x": (_i, [_FM, _FM, _P]),
+    "tdvc_avgpool2": (_i, [_FM, _FM, _P]),
+    "tdvc_spynet_level_input": (_i, [_FM, _FM, _FM, _FM, _FM, _P]),
+    "tdvc_resize_bilinear": (_i, [_FM, _FM, _P, _P]),
+    "tdvc_avgpool_k": (_i, [_FM, _i, _P, _i, _i, _P]),
+    "tdvc_patch_match": (_i, [_P, _P, _i, _i, _i, _i, _P, _P]),
+    "tdvc_match_gather": (_i, [_FM, _FM, _P, _i, _i, _i, _FM, _P]),
+    "tdvc_eb_forward": (_i, [_FM, _P, _FM, _FM, _P, _P, _i, _P]),
+    "tdvc_gc_forward": (_i, [_FM, _FM, _FM, _P, _P, _i, _P]),
+    "tdvc_quantize": (_i, [_FM, _FM, _FM, _P]),
+    "tdvc_rans_encode": (_i64, [_P, _P, _i64, _P, C.c_int32, _P, _P, _P, _i64]),
+    "tdvc_rans_decode": (_i, [_P, _i64, _P, _i64, _P, C.c_int32, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class TdvcHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raise if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TdvcHipError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  tdvc_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)        # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().tdvc_last_error().decode("utf-8", "replace")
+        raise TdvcHipError(f"{what}: rc={rc}: {msg}")

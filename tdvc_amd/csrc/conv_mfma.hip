@@ -1,0 +1,379 @@
+// Implicit-GEMM convolution on MFMA for gfx950 — the conv analysis/synthesis transforms,
+// feature extractors, SPyNet 7x7 stacks, masked context conv, GDN norm pools (SURVEY §8 a2-a9,
+// a13-a15).  fp16 NHWC in, fp32 accumulate, fused epilogue.
+//
+//   D[cout][pixel] = sum_{tap, cin} W[cout][tap][cin] * X[pixel + tap][cin]
+//
+// MFMA roles: A = weights (rows = cout), B = activations (cols = pixels), so that a lane's 16
+// accumulator registers hold 4 groups of 4 CONSECUTIVE output channels of ONE pixel -> 8-byte
+// NHWC stores (v_mfma_f32_32x32x16_f16: C/D col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)).
+//
+// Work decomposition: one 256-thread workgroup (4 waves) = 8x32 output pixels x (MT*32) output
+// channels; wave w owns output rows 2w, 2w+1.  The input halo tile of one channel chunk (CK
+// channels) is staged once in LDS and re-read by every tap (9x / 25x / 49x reuse); LDS pixel
+// stride is CK*2+16 bytes so that the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte
+// slots (conflict-free).  Stride-2 convs de-interleave columns by parity while staging so the
+// same holds.  Weights are pre-packed on the host in MFMA fragment order: one wave-wide 1 KiB
+// coalesced global_load_dwordx4 per fragment, served from L2 (a layer's weights are <= 0.6 MB).
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 32;
+
+struct ConvParams {
+  const half_t* x; long x_sn; int x_sp; int H, W, Cin;
+  const half_t* w; const float* bias;
+  FMap y; int Ho, Wo; int cout;
+  FMap aux; FMap res; FMap res2;
+  int ntaps, kh, kw, pad;
+  int nchunks, steps;   // steps per chunk
+  int square, gdn, act; float slope; int round16, out_mode;
+  int tiles_x;
+  int8_t tap_dy[TDVC_MAX_TAPS], tap_dx[TDVC_MAX_TAPS];
+};
+
+template <int CK8, int MT, int STRIDE>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int CK = CK8 * 8;
+  constexpr int PS = (CK8 == 1) ? 16 : CK * 2 + 16;  // LDS bytes per staged pixel
+  int* tapoff = reinterpret_cast<int*>(smem);          // [49], first 256 bytes
+  unsigned char* tile = smem + 256;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, r = lane & 31;
+  const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
+  const int cb = blockIdx.y, n = blockIdx.z;
+
+  const int TIH = (TH - 1) * STRIDE + p.kh;
+  const int TIW = (TW - 1) * STRIDE + p.kw;
+  const int HALFW = (TIW + 1) >> 1;
+  const int TIWp = (STRIDE == 2) ? 2 * HALFW : TIW;
+
+  if (tid < p.ntaps) {
+    const int dy = p.tap_dy[tid], dx = p.tap_dx[tid];
+    tapoff[tid] = (STRIDE == 2) ? (dy * TIWp + (dx & 1) * HALFW + (dx >> 1)) * PS : (dy * TIWp + dx) * PS;
+  }
+
+  int base[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) base[nt] = (((wave * 2 + nt) * STRIDE) * TIWp + r) * PS;
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+
+  const half_t* xn = p.x + (long)n * p.x_sn;
+  const int iy0 = ty * TH * STRIDE - p.pad, ix0 = tx * TW * STRIDE - p.pad;
+  const int total = TIH * TIW * CK8;
+
+  for (int ch = 0; ch < p.nchunks; ++ch) {
+    if (ch > 0) __syncthreads();
+    // ---- stage the halo tile of channels [ch*CK, ch*CK+CK) ------------------------------
+    for (int idx = tid; idx < total; idx += 256) {
+      const int c8 = idx % CK8;
+      const int pix = idx / CK8;
+      const int c = pix % TIW, rr = pix / TIW;
+      const int iy = iy0 + rr, ix = ix0 + c;
+      const int cg = ch * CK + c8 * 8;
+      half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && cg < p.Cin)
+        v = *reinterpret_cast<const half8*>(xn + ((long)iy * p.W + ix) * p.x_sp + cg);
+      if (p.square) v = v * v;
+      const int cpos = (STRIDE == 2) ? ((c & 1) * HALFW + (c >> 1)) : c;
+      *reinterpret_cast<half8*>(tile + (rr * TIWp + cpos) * PS + c8 * 16) = v;
+    }
+    __syncthreads();
+
+    // ---- MFMA over (tap, channel) for this chunk ------------------------------------------
+    const half_t* wp[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      wp[mt] = p.w + ((((long)(cb * MT + mt) * p.nchunks + ch) * p.steps) * 64 + lane) * 8;
+
+    if constexpr (CK8 == 1) {
+      for (int s = 0; s < p.steps; ++s) {
+        int tap = 2 * s + hh;
+        tap = tap < p.ntaps ? tap : p.ntaps - 1;   // padded k-chunk: its weights are zero
+        const int toff = tapoff[tap];
+        half8 a[MT], b[2];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { a[mt] = *reinterpret_cast<const half8*>(wp[mt]); wp[mt] += 512; }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) b[nt] = *reinterpret_cast<const half8*>(tile + base[nt] + toff);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+      }
+    } else {
+      for (int tap = 0; tap < p.ntaps; ++tap) {
+        const int toff = tapoff[tap] + hh * 16;
+#pragma unroll
+        for (int s2 = 0; s2 < CK8 / 2; ++s2) {
+          half8 a[MT], b[2];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) { a[mt] = *reinterpret_cast<const half8*>(wp[mt]); wp[mt] += 512; }
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            b[nt] = *reinterpret_cast<const half8*>(tile + base[nt] + toff + s2 * 32);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------
+  const int ox = tx * TW + r;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int oy = ty * TH + wave * 2 + nt;
+    if (oy >= p.Ho || ox >= p.Wo) continue;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = (cb * MT + mt) * 32 + 8 * g + 4 * hh;   // 4 consecutive channels co..co+3
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[mt][nt][4 * g + i];
+        if (p.bias) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] += b4[i];
+        }
+        // output geometry
+        int py = oy, px = ox, pc = co, PW = p.Wo;
+        if (p.out_mode == TDVC_OUT_SHUFFLE2) {
+          const int cq = p.cout >> 2;            // channels after the shuffle
+          const int sub = co / cq;               // host permutes rows: packed = (i*2+j)*cq + c
+          pc = co - sub * cq;
+          py = 2 * oy + (sub >> 1);
+          px = 2 * ox + (sub & 1);
+          PW = 2 * p.Wo;
+        }
+        if (p.gdn) {
+          const half_t* ap = reinterpret_cast<const half_t*>(p.aux.p) + (long)n * p.aux.sn + ((long)oy * p.Wo + ox) * p.aux.sp + co;
+          const half4 a4 = *reinterpret_cast<const half4*>(ap);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            v[i] = (float)a4[i] * (p.gdn == TDVC_GDN_FWD ? rsqrtf(v[i]) : sqrtf(v[i]));
+        }
+        if (p.round16) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = (float)(half_t)v[i];
+        }
+        if (p.act) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = act_apply(v[i], p.act, p.slope);
+        }
+        const long opix = (long)py * PW + px;
+        if (p.res.p) {
+          if (p.res.f32) {
+            const float* rp = reinterpret_cast<const float*>(p.res.p) + (long)n * p.res.sn + opix * p.res.sp + pc;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (pc + i < p.res.C) v[i] += rp[i];
+          } else if (pc < p.res.C) {
+            const half4 r4 = *reinterpret_cast<const half4*>(reinterpret_cast<const half_t*>(p.res.p) + (long)n * p.res.sn + opix * p.res.sp + pc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += (float)r4[i];
+          }
+        }
+        if (p.res2.p && pc < p.res2.C) {
+          const half4 r4 = *reinterpret_cast<const half4*>(reinterpret_cast<const half_t*>(p.res2.p) + (long)n * p.res2.sn + opix * p.res2.sp + pc);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] += (float)r4[i];
+        }
+        if (p.out_mode == TDVC_OUT_NCHW_F32) {
+          float* yp = reinterpret_cast<float*>(p.y.p);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (co + i < p.cout) yp[(((long)n * p.cout + co + i) * p.Ho + oy) * p.Wo + ox] = v[i];
+        } else if (p.y.f32) {
+          float* yp = reinterpret_cast<float*>(p.y.p) + (long)n * p.y.sn + opix * p.y.sp + pc;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (pc + i < p.y.C) yp[i] = v[i];
+        } else if (pc < p.y.C) {
+          half4 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = (half_t)v[i];
+          *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.y.p) + (long)n * p.y.sn + opix * p.y.sp + pc) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int CK8, int MT, int STRIDE>
+int launch(const ConvParams& p, dim3 grid, size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL((conv_mfma_kernel<CK8, MT, STRIDE>), grid, dim3(256), lds, st, p);
+  return tdvc_launch_status("tdvc_conv2d");
+}
+
+template <int CK8, int MT>
+int launch_s(const ConvParams& p, int stride, dim3 grid, size_t lds, hipStream_t st) {
+  return stride == 1 ? launch<CK8, MT, 1>(p, grid, lds, st) : launch<CK8, MT, 2>(p, grid, lds, st);
+}
+
+template <int CK8>
+int launch_m(const ConvParams& p, int mt, int stride, dim3 grid, size_t lds, hipStream_t st) {
+  return mt == 1 ? launch_s<CK8, 1>(p, stride, grid, lds, st) : launch_s<CK8, 2>(p, stride, grid, lds, st);
+}
+
+inline int lds_bytes(int ck, int kh, int kw, int stride) {
+  const int ps = (ck == 8) ? 16 : ck * 2 + 16;
+  const int tih = (TH - 1) * stride + kh, tiw = (TW - 1) * stride + kw;
+  const int tiwp = stride == 2 ? 2 * ((tiw + 1) >> 1) : tiw;
+  return 256 + tih * tiwp * ps;
+}
+
+inline int cout_tiles(int cout) { return cout <= 32 ? 1 : 2 * ((cout + 63) / 64); }
+
+}  // namespace
+
+extern "C" int tdvc_conv_plan(int cin, int kh, int kw, int stride) {
+  if (cin <= 0 || (cin % 8) != 0 || kh < 1 || kw < 1 || kh > 7 || kw > 7 || (stride != 1 && stride != 2)) {
+    tdvc_set_error("tdvc_conv_plan: unsupported geometry cin=%d k=%dx%d stride=%d", cin, kh, kw, stride);
+    return TDVC_EINVAL;
+  }
+  const int cands[4] = {64, 32, 16, 8};
+  for (int i = 0; i < 4; ++i) {
+    const int ck = cands[i];
+    if (ck > cin && ck != 8) {
+      // do not stage more channels than exist unless cin is not a power-of-two multiple
+      if (cin % ck != 0 && cin < ck) continue;
+    }
+    if (lds_bytes(ck, kh, kw, stride) <= 64 * 1024) return ck;
+  }
+  tdvc_set_error("tdvc_conv_plan: no LDS plan for k=%dx%d stride=%d", kh, kw, stride);
+  return TDVC_EINVAL;
+}
+
+extern "C" int64_t tdvc_conv_packed_bytes(int cout, int cin, int ntaps, int ck) {
+  if (cout <= 0 || cin <= 0 || ntaps <= 0 || ntaps > TDVC_MAX_TAPS || (ck != 8 && ck != 16 && ck != 32 && ck != 64)) return TDVC_EINVAL;
+  const int ck8 = ck / 8;
+  const int64_t nchunks = (cin + ck - 1) / ck;
+  const int64_t steps = (ntaps * ck8 + 1) / 2;
+  return (int64_t)cout_tiles(cout) * nchunks * steps * 64 * 8 * 2;
+}
+
+extern "C" int tdvc_pack_conv_weights(const float* w, int cout, int cin_real, int cin, int kh, int kw,
+                                      int ntaps, const int8_t* tap_dy, const int8_t* tap_dx, int ck, uint16_t* dst) {
+  TDVC_CHECK(w && dst && tap_dy && tap_dx, "tdvc_pack_conv_weights: null pointer");
+  TDVC_CHECK(tdvc_conv_packed_bytes(cout, cin, ntaps, ck) > 0, "tdvc_pack_conv_weights: bad geometry");
+  TDVC_CHECK(cin_real <= cin, "tdvc_pack_conv_weights: cin_real > cin");
+  const int ck8 = ck / 8;
+  const int nchunks = (cin + ck - 1) / ck;
+  const int steps = (ntaps * ck8 + 1) / 2;
+  const int tiles = cout_tiles(cout);
+  half_t* out = reinterpret_cast<half_t*>(dst);
+  for (int t = 0; t < tiles; ++t)
+    for (int ch = 0; ch < nchunks; ++ch)
+      for (int s = 0; s < steps; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int r = lane & 31, h = lane >> 5;
+          const int co = t * 32 + r;
+          const int kc = 2 * s + h;
+          half_t* o = out + ((((int64_t)t * nchunks + ch) * steps + s) * 64 + lane) * 8;
+          for (int j = 0; j < 8; ++j) {
+            float v = 0.f;
+            if (kc < ntaps * ck8 && co < cout) {
+              const int tap = kc / ck8, c8 = kc % ck8;
+              const int ci = ch * ck + c8 * 8 + j;
+              const int dy = tap_dy[tap], dx = tap_dx[tap];
+              if (ci < cin_real && dy >= 0 && dy < kh && dx >= 0 && dx < kw)
+                v = w[(((int64_t)co * cin_real + ci) * kh + dy) * kw + dx];
+            }
+            o[j] = (half_t)v;
+          }
+        }
+  return TDVC_OK;
+}
+
+extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
+  TDVC_CHECK(d, "tdvc_conv2d: null descriptor");
+  TDVC_CHECK(fmap_ok16(d->x), "tdvc_conv2d: input must be an fp16 fmap with C,sp %% 8 == 0 and 16-byte aligned");
+  TDVC_CHECK(d->w && aligned16(d->w), "tdvc_conv2d: weights null/unaligned");
+  TDVC_CHECK(d->stride == 1 || d->stride == 2, "tdvc_conv2d: stride %d unsupported", d->stride);
+  TDVC_CHECK(d->ntaps >= 1 && d->ntaps <= TDVC_MAX_TAPS && d->kh >= 1 && d->kh <= 7 && d->kw >= 1 && d->kw <= 7,
+             "tdvc_conv2d: bad kernel %dx%d ntaps=%d", d->kh, d->kw, d->ntaps);
+  TDVC_CHECK(d->ck == 8 || d->ck == 16 || d->ck == 32 || d->ck == 64, "tdvc_conv2d: bad ck %d", d->ck);
+  TDVC_CHECK(d->cout >= 1, "tdvc_conv2d: cout");
+  for (int t = 0; t < d->ntaps; ++t)
+    TDVC_CHECK(d->tap_dy[t] >= 0 && d->tap_dy[t] < d->kh && d->tap_dx[t] >= 0 && d->tap_dx[t] < d->kw,
+               "tdvc_conv2d: tap %d out of the %dx%d window", t, d->kh, d->kw);
+  const int Ho = (d->x.H + 2 * d->pad - d->kh) / d->stride + 1;
+  const int Wo = (d->x.W + 2 * d->pad - d->kw) / d->stride + 1;
+  TDVC_CHECK(Ho > 0 && Wo > 0, "tdvc_conv2d: empty output");
+  const int lds = lds_bytes(d->ck, d->kh, d->kw, d->stride);
+  TDVC_CHECK(lds <= 64 * 1024, "tdvc_conv2d: LDS plan %d bytes too large (use tdvc_conv_plan)", lds);
+
+  const int shuf = d->out_mode == TDVC_OUT_SHUFFLE2;
+  if (d->out_mode == TDVC_OUT_NCHW_F32) {
+    TDVC_CHECK(d->y.p && d->y.N == d->x.N, "tdvc_conv2d: NCHW output null / batch mismatch");
+  } else {
+    TDVC_CHECK(d->y.dtype == TDVC_F32 ? fmap_ok32(d->y) : fmap_ok16(d->y), "tdvc_conv2d: bad output fmap");
+    TDVC_CHECK(d->y.N == d->x.N && d->y.H == (shuf ? 2 * Ho : Ho) && d->y.W == (shuf ? 2 * Wo : Wo),
+               "tdvc_conv2d: output geometry %dx%d does not match conv result %dx%d%s", d->y.H, d->y.W, Ho, Wo,
+               shuf ? " (x2 shuffle)" : "");
+    if (shuf) TDVC_CHECK((d->cout % 128) == 0, "tdvc_conv2d: SHUFFLE2 needs cout %% 128 == 0");
+    if (d->y.dtype == TDVC_F16) TDVC_CHECK((d->y.C % 8) == 0, "tdvc_conv2d: fp16 output C %% 8");
+  }
+  if (d->gdn) {
+    TDVC_CHECK(fmap_ok16(d->aux) && d->aux.H == Ho && d->aux.W == Wo && d->aux.N == d->x.N && d->aux.C >= d->cout &&
+                   !shuf && (d->cout % 64) == 0,
+               "tdvc_conv2d: GDN aux fmap mismatch");
+  }
+  if (d->res.p) {
+    TDVC_CHECK(d->res.dtype == TDVC_F32 ? fmap_ok32(d->res) : fmap_ok16(d->res), "tdvc_conv2d: bad residual fmap");
+    TDVC_CHECK(d->res.N == d->x.N && d->res.H == (shuf ? 2 * Ho : Ho) && d->res.W == (shuf ? 2 * Wo : Wo),
+               "tdvc_conv2d: residual geometry mismatch");
+  }
+  if (d->res2.p) {
+    TDVC_CHECK(fmap_ok16(d->res2) && d->res2.N == d->x.N && d->res2.H == (shuf ? 2 * Ho : Ho) && d->res2.W == (shuf ? 2 * Wo : Wo),
+               "tdvc_conv2d: bad second residual fmap");
+  }
+  if (d->bias) TDVC_CHECK(aligned16(d->bias), "tdvc_conv2d: bias unaligned");
+
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = reinterpret_cast<const half_t*>(d->x.p); p.x_sn = d->x.sn; p.x_sp = d->x.sp;
+  p.H = d->x.H; p.W = d->x.W; p.Cin = d->x.C;
+  p.w = reinterpret_cast<const half_t*>(d->w); p.bias = d->bias;
+  p.y = to_dev(d->y); p.Ho = Ho; p.Wo = Wo; p.cout = d->cout;
+  p.aux = d->gdn ? to_dev(d->aux) : null_fmap();
+  p.res = d->res.p ? to_dev(d->res) : null_fmap();
+  p.res2 = d->res2.p ? to_dev(d->res2) : null_fmap();
+  p.ntaps = d->ntaps; p.kh = d->kh; p.kw = d->kw; p.pad = d->pad;
+  const int ck8 = d->ck / 8;
+  p.nchunks = (d->x.C + d->ck - 1) / d->ck;
+  p.steps = (d->ntaps * ck8 + 1) / 2;
+  p.square = d->square_input; p.gdn = d->gdn; p.act = d->act; p.slope = d->slope;
+  p.round16 = d->round_before_act; p.out_mode = d->out_mode;
+  memcpy(p.tap_dy, d->tap_dy, sizeof(p.tap_dy));
+  memcpy(p.tap_dx, d->tap_dx, sizeof(p.tap_dx));
+  const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
+  p.tiles_x = tiles_x;
+  const int tiles = cout_tiles(d->cout);
+  const int mt = tiles == 1 ? 1 : 2;
+  dim3 grid(tiles_x * tiles_y, tiles / mt, d->x.N);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  switch (ck8) {
+    case 1: return launch_m<1>(p, mt, d->stride, grid, lds, st);
+    case 2: return launch_m<2>(p, mt, d->stride, grid, lds, st);
+    case 4: return launch_m<4>(p, mt, d->stride, grid, lds, st);
+    default: return launch_m<8>(p, mt, d->stride, grid, lds, st);
+  }
+}

@@ -1,0 +1,724 @@
+// HBM-bound kernels of the TDVC hot path for gfx950: layout conversion, SE attention, bilinear
+// resampling, the SPyNet warp (flow_warp), in-loop-filter patch matching and the entropy-model
+// rate terms.  All are streaming kernels: channel-innermost fmaps, 16-byte accesses per lane,
+// one pass over the data, reductions through wave shuffles / LDS with deterministic two-stage sums.
+#include "common.h"
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+
+__device__ __forceinline__ void load8(const FMap& f, int n, long pix, int c, float v[8]) {
+  if (f.f32) {
+    const float* p = reinterpret_cast<const float*>(f.p) + (long)n * f.sn + pix * f.sp + c;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (c + j < f.C) ? p[j] : 0.f;
+  } else {
+    const half8 h = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(f.p) + (long)n * f.sn + pix * f.sp + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+  }
+}
+__device__ __forceinline__ void store8(const FMap& f, int n, long pix, int c, const float v[8]) {
+  if (f.f32) {
+    float* p = reinterpret_cast<float*>(f.p) + (long)n * f.sn + pix * f.sp + c;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (c + j < f.C) p[j] = v[j];
+  } else {
+    half8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
+    *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(f.p) + (long)n * f.sn + pix * f.sp + c) = h;
+  }
+}
+
+inline dim3 grid1d(long total, int block = EW_BLOCK) { return dim3((unsigned)((total + block - 1) / block)); }
+
+// ------------------------------------------------------------------ layout
+__global__ void nchw_to_fmap_kernel(const float* src, int C, FMap y) {
+  const long npix = (long)y.H * y.W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * y.N) return;
+  const int n = (int)(i / npix);
+  const long pix = i % npix;
+  for (int c0 = 0; c0 < y.C; c0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (c0 + j < C) ? src[((long)n * C + c0 + j) * npix + pix] : 0.f;
+    store8(y, n, pix, c0, v);
+  }
+}
+
+__global__ void fmap_to_nchw_kernel(FMap x, int C, float* dst) {
+  const long npix = (long)x.H * x.W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * x.N) return;
+  const int n = (int)(i / npix);
+  const long pix = i % npix;
+  for (int c0 = 0; c0 < C; c0 += 8) {
+    float v[8];
+    load8(x, n, pix, c0, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (c0 + j < C) dst[((long)n * C + c0 + j) * npix + pix] = v[j];
+  }
+}
+
+// ------------------------------------------------------------------ elementwise
+__global__ void scale_act_res_kernel(FMap a, const float* gate, int act, float slope, FMap r, float rs, FMap y, FMap y2) {
+  const int chunks = (a.C + 7) / 8;
+  const long npix = (long)a.H * a.W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * chunks * a.N) return;
+  const int c = (int)(i % chunks) * 8;
+  const long t = i / chunks;
+  const long pix = t % npix;
+  const int n = (int)(t / npix);
+  float v[8];
+  load8(a, n, pix, c, v);
+  if (gate) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (c + j < a.C) v[j] *= gate[(long)n * a.C + c + j];
+  }
+  if (act) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = act_apply(v[j], act, slope);
+  }
+  if (r.p) {
+    float q[8];
+    load8(r, n, pix, c, q);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += rs * q[j];
+  }
+  store8(y, n, pix, c, v);
+  if (y2.p) store8(y2, n, pix, c, v);
+}
+
+__global__ void add_flow_kernel(FMap off, FMap flow) {
+  const int chunks = off.C / 8;
+  const long npix = (long)off.H * off.W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * chunks * off.N) return;
+  const int c = (int)(i % chunks) * 8;
+  const long t = i / chunks;
+  const long pix = t % npix;
+  const int n = (int)(t / npix);
+  const float* fp = reinterpret_cast<const float*>(flow.p) + (long)n * flow.sn + pix * flow.sp;
+  const float fx = fp[0], fy = fp[1];
+  float v[8];
+  load8(off, n, pix, c, v);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] += (j & 1) ? fy : fx;
+  store8(off, n, pix, c, v);
+}
+
+__global__ void bcast_add_act_kernel(FMap x, FMap b, float slope) {
+  const int chunks = x.C / 8;
+  const long npix = (long)x.H * x.W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * chunks * x.N) return;
+  const int c = (int)(i % chunks) * 8;
+  const long t = i / chunks;
+  const long pix = t % npix;
+  const int n = (int)(t / npix);
+  float v[8], q[8];
+  load8(x, n, pix, c, v);
+  load8(b, n, pix, c % b.C, q);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = act_apply(v[j] + q[j], TDVC_ACT_LRELU, slope);
+  store8(x, n, pix, c, v);
+}
+
+// ------------------------------------------------------------------ SE attention
+// partial[n][blk][c] = sum over the block's pixel range
+__global__ __launch_bounds__(256) void channel_sum_kernel(FMap x, float* partial, int nblocks) {
+  __shared__ float red[256][9];
+  const int chunks = x.C / 8;            // <= 32
+  const int lanes = 256 / chunks;        // pixel lanes
+  const int tid = threadIdx.x;
+  const int ck = tid % chunks, pl = tid / chunks;
+  const int n = blockIdx.y;
+  const long npix = (long)x.H * x.W;
+  const long per = (npix + nblocks - 1) / nblocks;
+  const long p0 = (long)blockIdx.x * per;
+  const long p1 = p0 + per < npix ? p0 + per : npix;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (pl < lanes) {
+    for (long pix = p0 + pl; pix < p1; pix += lanes) {
+      float v[8];
+      load8(x, n, pix, ck * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[tid][j] = (pl < lanes) ? acc[j] : 0.f;
+  __syncthreads();
+  if (tid < x.C) {
+    const int c = tid, cc = c / 8, j = c % 8;
+    float s = 0.f;
+    for (int l = 0; l < lanes; ++l) s += red[l * chunks + cc][j];
+    partial[((long)n * nblocks + blockIdx.x) * x.C + c] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* partial, int nblocks, float inv_count, int C, int Cmid,
+                                                       const float* w1, const float* b1, const float* w2, const float* b2,
+                                                       float* gate) {
+  __shared__ float mean[256];
+  __shared__ float mid[32];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  if (tid < C) {
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partial[((long)n * nblocks + b) * C + tid];
+    mean[tid] = s * inv_count;
+  }
+  __syncthreads();
+  if (tid < Cmid) {
+    float s = b1[tid];
+    for (int c = 0; c < C; ++c) s += w1[tid * C + c] * mean[c];
+    mid[tid] = s > 0.f ? s : 0.f;
+  }
+  __syncthreads();
+  if (tid < C) {
+    float s = b2[tid];
+    for (int j = 0; j < Cmid; ++j) s += w2[tid * Cmid + j] * mid[j];
+    gate[(long)n * C + tid] = 1.f / (1.f + expf(-s));
+  }
+}
+
+// ------------------------------------------------------------------ resampling
+__global__ void upsample2x_kernel(FMap x, FMap y) {
+  const int chunks = x.C / 8;
+  const long npix = (long)y.H * y.W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * chunks * y.N) return;
+  const int c = (int)(i % chunks) * 8;
+  const long t = i / chunks;
+  const long pix = t % npix;
+  const int n = (int)(t / npix);
+  const int oy = (int)(pix / y.W), ox = (int)(pix % y.W);
+  const float sy = fmaxf((oy + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((ox + 0.5f) * 0.5f - 0.5f, 0.f);
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = y0 + (y0 < x.H - 1), x1 = x0 + (x0 < x.W - 1);
+  const float ly1 = sy - y0, lx1 = sx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+  float a[8], b[8], cc[8], d[8], v[8];
+  load8(x, n, (long)y0 * x.W + x0, c, a);
+  load8(x, n, (long)y0 * x.W + x1, c, b);
+  load8(x, n, (long)y1 * x.W + x0, c, cc);
+  load8(x, n, (long)y1 * x.W + x1, c, d);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = ly0 * (lx0 * a[j] + lx1 * b[j]) + ly1 * (lx0 * cc[j] + lx1 * d[j]);
+  store8(y, n, pix, c, v);
+}
+
+__global__ void avgpool2_kernel(FMap x, FMap y) {
+  const long npix = (long)y.H * y.W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * y.N) return;
+  const int n = (int)(i / npix);
+  const long pix = i % npix;
+  const int oy = (int)(pix / y.W), ox = (int)(pix % y.W);
+  const float* xp = reinterpret_cast<const float*>(x.p) + (long)n * x.sn;
+  float* yp = reinterpret_cast<float*>(y.p) + (long)n * y.sn + pix * y.sp;
+  const long p00 = ((long)(2 * oy) * x.W + 2 * ox) * x.sp, p10 = p00 + (long)x.W * x.sp;
+  for (int c = 0; c < y.C; ++c)
+    yp[c] = (xp[p00 + c] + xp[p00 + x.sp + c] + xp[p10 + c] + xp[p10 + x.sp + c]) * 0.25f;
+}
+
+// flow_up (x2, align_corners=True, *2) + border-clamped bilinear warp + 8-channel assembly
+__global__ void spynet_level_input_kernel(FMap ref, FMap supp, FMap flow_lo, FMap flow_up, FMap cat8) {
+  const int H = ref.H, W = ref.W;
+  const long npix = (long)H * W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * ref.N) return;
+  const int n = (int)(i / npix);
+  const long pix = i % npix;
+  const int y = (int)(pix / W), x = (int)(pix % W);
+  float fx = 0.f, fy = 0.f;
+  if (flow_lo.p) {
+    const int h2 = flow_lo.H, w2 = flow_lo.W;
+    const float ry = (H > 1) ? (float)(h2 - 1) / (float)(H - 1) : 0.f;
+    const float rx = (W > 1) ? (float)(w2 - 1) / (float)(W - 1) : 0.f;
+    const float sy = ry * y, sx = rx * x;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < h2 - 1), x1 = x0 + (x0 < w2 - 1);
+    const float ly1 = sy - y0, lx1 = sx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const float* fl = reinterpret_cast<const float*>(flow_lo.p) + (long)n * flow_lo.sn;
+    const float* a = fl + ((long)y0 * w2 + x0) * flow_lo.sp;
+    const float* b = fl + ((long)y0 * w2 + x1) * flow_lo.sp;
+    const float* c = fl + ((long)y1 * w2 + x0) * flow_lo.sp;
+    const float* d = fl + ((long)y1 * w2 + x1) * flow_lo.sp;
+    fx = (ly0 * (lx0 * a[0] + lx1 * b[0]) + ly1 * (lx0 * c[0] + lx1 * d[0])) * 2.0f;
+    fy = (ly0 * (lx0 * a[1] + lx1 * b[1]) + ly1 * (lx0 * c[1] + lx1 * d[1])) * 2.0f;
+  }
+  // grid_sample(bilinear, border, align_corners=True) through the normalise / unnormalise round trip
+  const float gx = (float)x + fx, gy = (float)y + fy;
+  const float wm = (float)(W - 1 > 1 ? W - 1 : 1), hm = (float)(H - 1 > 1 ? H - 1 : 1);
+  const float nx = 2.0f * gx / wm - 1.0f, ny = 2.0f * gy / hm - 1.0f;
+  float ix = ((nx + 1.f) / 2.f) * (float)(W - 1), iy = ((ny + 1.f) / 2.f) * (float)(H - 1);
+  ix = fminf((float)(W - 1), fmaxf(ix, 0.f));
+  iy = fminf((float)(H - 1), fmaxf(iy, 0.f));
+  const float xw = floorf(ix), yn = floorf(iy);
+  const int ix0 = (int)xw, iy0 = (int)yn, ix1 = ix0 + 1, iy1 = iy0 + 1;
+  const float w_nw = ((float)ix1 - ix) * ((float)iy1 - iy), w_ne = (ix - (float)ix0) * ((float)iy1 - iy);
+  const float w_sw = ((float)ix1 - ix) * (iy - (float)iy0), w_se = (ix - (float)ix0) * (iy - (float)iy0);
+  const float* sp = reinterpret_cast<const float*>(supp.p) + (long)n * supp.sn;
+  float wv[3] = {0.f, 0.f, 0.f};
+  const bool x0ok = ix0 >= 0 && ix0 < W, x1ok = ix1 >= 0 && ix1 < W, y0ok = iy0 >= 0 && iy0 < H, y1ok = iy1 >= 0 && iy1 < H;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float s = 0.f;
+    if (y0ok && x0ok) s += sp[((long)iy0 * W + ix0) * supp.sp + c] * w_nw;
+    if (y0ok && x1ok) s += sp[((long)iy0 * W + ix1) * supp.sp + c] * w_ne;
+    if (y1ok && x0ok) s += sp[((long)iy1 * W + ix0) * supp.sp + c] * w_sw;
+    if (y1ok && x1ok) s += sp[((long)iy1 * W + ix1) * supp.sp + c] * w_se;
+    wv[c] = s;
+  }
+  const float* rp = reinterpret_cast<const float*>(ref.p) + (long)n * ref.sn + pix * ref.sp;
+  float v[8] = {rp[0], rp[1], rp[2], wv[0], wv[1], wv[2], fx, fy};
+  store8(cat8, n, pix, 0, v);
+  float* fu = reinterpret_cast<float*>(flow_up.p) + (long)n * flow_up.sn + pix * flow_up.sp;
+  fu[0] = fx;
+  fu[1] = fy;
+}
+
+__global__ void resize_bilinear_kernel(FMap x, FMap y, const float* chscale) {
+  const long npix = (long)y.H * y.W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * y.N) return;
+  const int n = (int)(i / npix);
+  const long pix = i % npix;
+  const int oy = (int)(pix / y.W), ox = (int)(pix % y.W);
+  const float rh = (float)x.H / (float)y.H, rw = (float)x.W / (float)y.W;
+  const float sy = fmaxf(rh * (oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(rw * (ox + 0.5f) - 0.5f, 0.f);
+  const int y0 = (int)sy < x.H - 1 ? (int)sy : x.H - 1, x0 = (int)sx < x.W - 1 ? (int)sx : x.W - 1;
+  const int y1 = y0 + (y0 < x.H - 1), x1 = x0 + (x0 < x.W - 1);
+  const float ly1 = sy - y0, lx1 = sx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+  const float* xp = reinterpret_cast<const float*>(x.p) + (long)n * x.sn;
+  float* yp = reinterpret_cast<float*>(y.p) + (long)n * y.sn + pix * y.sp;
+  for (int c = 0; c < y.C; ++c) {
+    const float a = xp[((long)y0 * x.W + x0) * x.sp + c], b = xp[((long)y0 * x.W + x1) * x.sp + c];
+    const float cc = xp[((long)y1 * x.W + x0) * x.sp + c], d = xp[((long)y1 * x.W + x1) * x.sp + c];
+    float v = ly0 * (lx0 * a + lx1 * b) + ly1 * (lx0 * cc + lx1 * d);
+    if (chscale) v *= chscale[c];
+    yp[c] = v;
+  }
+}
+
+// ------------------------------------------------------------------ in-loop filter matching
+// one block per pooled cell: mean over scale x scale pixels of every channel
+__global__ __launch_bounds__(256) void avgpool_k_kernel(FMap x, int scale, float* pooled, int hp, int wp) {
+  __shared__ float red[256][9];
+  const int chunks = x.C / 8;
+  const int lanes = 256 / chunks;
+  const int tid = threadIdx.x;
+  const int ck = tid % chunks, pl = tid / chunks;
+  const int cell = blockIdx.x, n = blockIdx.y;
+  const int py = cell / wp, px = cell % wp;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  const int area = scale * scale;
+  if (pl < lanes) {
+    for (int k = pl; k < area; k += lanes) {
+      const int yy = py * scale + k / scale, xx = px * scale + k % scale;
+      float v[8];
+      load8(x, n, (long)yy * x.W + xx, ck * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[tid][j] = (pl < lanes) ? acc[j] : 0.f;
+  __syncthreads();
+  if (tid < x.C) {
+    const int cc = tid / 8, j = tid % 8;
+    float s = 0.f;
+    for (int l = 0; l < lanes; ++l) s += red[l * chunks + cc][j];
+    pooled[(((long)n * hp + py) * wp + px) * x.C + tid] = s / (float)area;
+  }
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((tid & 63) == 0) sh[tid >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// patch (i,j) of a pooled map: rows 3i-3..3i-1, cols 3j-3..3j-1, zero outside (unfold k=3,s=3,p=3)
+__device__ __forceinline__ float patch_elem(const float* pm, int hp, int wp, int C, int pi, int pj, int d) {
+  const int c = d / 9, k = d % 9;
+  const int yy = 3 * pi - 3 + k / 3, xx = 3 * pj - 3 + k % 3;
+  if (yy < 0 || yy >= hp || xx < 0 || xx >= wp) return 0.f;
+  return pm[((long)yy * wp + xx) * C + c];
+}
+
+// grid (L, N); block 256.  idx[n][l] = argmax_m <a_l/|a_l|, b_m/|b_m|>, first index on ties
+__global__ __launch_bounds__(256) void patch_match_kernel(const float* pin, const float* pref, int hp, int wp, int C,
+                                                           int nph, int npw, int32_t* idx) {
+  extern __shared__ float sm[];
+  float* a = sm;                  // [C*9] normalised input patch
+  __shared__ float sh[4];
+  const int D = C * 9, L = nph * npw;
+  const int l = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const float* pa = pin + (long)n * hp * wp * C;
+  const float* pb = pref + (long)n * hp * wp * C;
+  float ss = 0.f;
+  for (int d = tid; d < D; d += 256) {
+    const float v = patch_elem(pa, hp, wp, C, l / npw, l % npw, d);
+    a[d] = v;
+    ss += v * v;
+  }
+  const float na = fmaxf(sqrtf(block_sum(ss, sh)), 1e-12f);
+  for (int d = tid; d < D; d += 256) a[d] = a[d] / na;
+  __syncthreads();
+  float best = -INFINITY;
+  int besti = 0;
+  for (int m = 0; m < L; ++m) {
+    float sb = 0.f;
+    for (int d = tid; d < D; d += 256) {
+      const float v = patch_elem(pb, hp, wp, C, m / npw, m % npw, d);
+      sb += v * v;
+    }
+    const float nb = fmaxf(sqrtf(block_sum(sb, sh)), 1e-12f);
+    float dot = 0.f;
+    for (int d = tid; d < D; d += 256) dot += a[d] * (patch_elem(pb, hp, wp, C, m / npw, m % npw, d) / nb);
+    const float s = block_sum(dot, sh);
+    if (s > best) { best = s; besti = m; }
+  }
+  if (tid == 0) idx[(long)n * L + l] = besti;
+}
+
+// 8 lanes per pixel (8 channels each, C = 64): gather matched block, cosine weight, write cat
+__global__ __launch_bounds__(256) void match_gather_kernel(FMap fin, FMap fref, const int32_t* idx, int ks, int nbh, int nbw, FMap cat) {
+  const int lanes = fin.C / 8;            // 8
+  const long npix = (long)fin.H * fin.W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long t = i / lanes;
+  const int c = (int)(i % lanes) * 8;
+  const bool valid = t < npix * fin.N;
+  const long tc = valid ? t : 0;
+  const int n = (int)(tc / npix);
+  const long pix = tc % npix;
+  const int y = (int)(pix / fin.W), x = (int)(pix % fin.W);
+  const int bi = y / ks + 1, bj = x / ks + 1;
+  const int m = idx[(long)n * nbh * nbw + bi * nbw + bj];
+  const int sy = (m / nbw - 1) * ks + y % ks, sx = (m % nbw - 1) * ks + x % ks;
+  float a[8], b[8];
+  load8(fin, n, pix, c, a);
+  if (sy >= 0 && sy < fref.H && sx >= 0 && sx < fref.W) {
+    load8(fref, n, (long)sy * fref.W + sx, c, b);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = 0.f;
+  }
+  float w12 = 0.f, w1 = 0.f, w2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { w12 += a[j] * b[j]; w1 += a[j] * a[j]; w2 += b[j] * b[j]; }
+  for (int o = 1; o < lanes; o <<= 1) {
+    w12 += __shfl_xor(w12, o);
+    w1 += __shfl_xor(w1, o);
+    w2 += __shfl_xor(w2, o);
+  }
+  const float cor = w12 / fmaxf(sqrtf(w1) * sqrtf(w2), 1e-8f);
+  if (!valid) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a[j] *= cor; b[j] *= cor; }
+  store8(cat, n, pix, c, a);
+  store8(cat, n, pix, fin.C + c, b);
+}
+
+// ------------------------------------------------------------------ entropy model
+constexpr int EB_NP = 59;   // floats per channel, see tdvc_amd/entropy.py::pack_eb_params
+
+__device__ __forceinline__ float eb_logits(const float* P, float v) {
+  // filters (1,3,3,3,3,1): m0[3], m1..m3[9], m4[3] | b0..b3[3], b4[1] | f0..f3[3] | median
+  const float* m = P;
+  const float* b = P + 33;
+  const float* f = P + 46;
+  float l[3], t[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    l[i] = m[i] * v + b[i];
+    l[i] += f[i] * tanhf(l[i]);
+  }
+#pragma unroll
+  for (int k = 1; k <= 3; ++k) {
+    const float* mk = m + 3 + (k - 1) * 9;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      t[i] = mk[i * 3 + 0] * l[0] + mk[i * 3 + 1] * l[1] + mk[i * 3 + 2] * l[2] + b[3 * k + i];
+      t[i] += f[3 * k + i] * tanhf(t[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) l[i] = t[i];
+  }
+  return m[30] * l[0] + m[31] * l[1] + m[32] * l[2] + b[12];
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void eb_forward_kernel(FMap z, const float* params, FMap noise, FMap z_hat, float* partial) {
+  __shared__ float sh[4];
+  const long npix = (long)z.H * z.W;
+  const long total = npix * z.C * z.N;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float bits = 0.f;
+  if (i < total) {
+    const int c = (int)(i % z.C);
+    const long t = i / z.C;
+    const long pix = t % npix;
+    const int n = (int)(t / npix);
+    const float* P = params + (long)c * EB_NP;
+    const float zv = reinterpret_cast<const float*>(z.p)[(long)n * z.sn + pix * z.sp + c];
+    float v;
+    if (noise.p) {
+      v = zv + reinterpret_cast<const float*>(noise.p)[(long)n * noise.sn + pix * noise.sp + c];
+    } else {
+      const float med = P[58];
+      v = rintf(zv - med) + med;
+    }
+    const float lower = eb_logits(P, v - 0.5f), upper = eb_logits(P, v + 0.5f);
+    const float s = lower + upper;
+    const float sign = s > 0.f ? -1.f : (s < 0.f ? 1.f : 0.f);
+    float lik = fabsf(sigmoidf_(sign * upper) - sigmoidf_(sign * lower));
+    lik = fmaxf(lik, 1e-9f);
+    bits = -log2f(lik);
+    if (z_hat.f32)
+      reinterpret_cast<float*>(z_hat.p)[(long)n * z_hat.sn + pix * z_hat.sp + c] = v;
+    else
+      reinterpret_cast<half_t*>(z_hat.p)[(long)n * z_hat.sn + pix * z_hat.sp + c] = (half_t)v;
+  }
+  const float s = block_sum(bits, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void gc_forward_kernel(FMap y, FMap gp, FMap noise, float* partial) {
+  __shared__ float sh[4];
+  const long npix = (long)y.H * y.W;
+  const long total = npix * y.C * y.N;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float bits = 0.f;
+  if (i < total) {
+    const int c = (int)(i % y.C);
+    const long t = i / y.C;
+    const long pix = t % npix;
+    const int n = (int)(t / npix);
+    const float yv = reinterpret_cast<const float*>(y.p)[(long)n * y.sn + pix * y.sp + c];
+    const float* g = reinterpret_cast<const float*>(gp.p) + (long)n * gp.sn + pix * gp.sp;
+    const float scale = fmaxf(g[c], 0.11f), mean = g[y.C + c];
+    float v;
+    if (noise.p)
+      v = yv + reinterpret_cast<const float*>(noise.p)[(long)n * noise.sn + pix * noise.sp + c] - mean;
+    else
+      v = rintf(yv - mean);
+    v = fabsf(v);
+    const float k = 0.70710678118654752440f;
+    const float upper = 0.5f * erfcf(-k * ((0.5f - v) / scale));
+    const float lower = 0.5f * erfcf(-k * ((-0.5f - v) / scale));
+    const float lik = fmaxf(upper - lower, 1e-9f);
+    bits = -log2f(lik);
+  }
+  const float s = block_sum(bits, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ void final_sum_kernel(const float* partial, int n, double* out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = sh[0];
+}
+
+__global__ void quantize_kernel(FMap y, FMap noise, FMap y_hat) {
+  const int chunks = (y.C + 7) / 8;
+  const long npix = (long)y.H * y.W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * chunks * y.N) return;
+  const int c = (int)(i % chunks) * 8;
+  const long t = i / chunks;
+  const long pix = t % npix;
+  const int n = (int)(t / npix);
+  float v[8];
+  load8(y, n, pix, c, v);
+  if (noise.p) {
+    float q[8];
+    load8(noise, n, pix, c, q);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += q[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = rintf(v[j]);
+  }
+  store8(y_hat, n, pix, c, v);
+}
+
+inline bool fmap_any(const tdvc_fmap& f) { return f.dtype == TDVC_F32 ? fmap_ok32(f) : fmap_ok16(f); }
+inline bool same_geom(const tdvc_fmap& a, const tdvc_fmap& b) { return a.N == b.N && a.H == b.H && a.W == b.W; }
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+}  // namespace
+
+extern "C" int tdvc_nchw_to_fmap(const float* src, int C, const tdvc_fmap* y, void* stream) {
+  TDVC_CHECK(src && y && fmap_any(*y) && C >= 1 && C <= y->C, "tdvc_nchw_to_fmap: bad arguments");
+  const long total = (long)y->N * y->H * y->W;
+  hipLaunchKernelGGL(nchw_to_fmap_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), src, C, to_dev(*y));
+  return tdvc_launch_status("tdvc_nchw_to_fmap");
+}
+
+extern "C" int tdvc_fmap_to_nchw(const tdvc_fmap* x, int C, float* dst, void* stream) {
+  TDVC_CHECK(dst && x && fmap_any(*x) && C >= 1 && C <= x->C, "tdvc_fmap_to_nchw: bad arguments");
+  const long total = (long)x->N * x->H * x->W;
+  hipLaunchKernelGGL(fmap_to_nchw_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*x), C, dst);
+  return tdvc_launch_status("tdvc_fmap_to_nchw");
+}
+
+extern "C" int tdvc_scale_act_res(const tdvc_fmap* a, const float* gate, int act, float slope,
+                                  const tdvc_fmap* r, float r_sign, const tdvc_fmap* y, const tdvc_fmap* y2, void* stream) {
+  TDVC_CHECK(a && y && fmap_any(*a) && fmap_any(*y) && same_geom(*a, *y) && y->C == a->C, "tdvc_scale_act_res: bad a/y");
+  if (r) TDVC_CHECK(fmap_any(*r) && same_geom(*a, *r) && r->C == a->C, "tdvc_scale_act_res: bad residual");
+  if (y2) TDVC_CHECK(fmap_any(*y2) && same_geom(*a, *y2) && y2->C == a->C, "tdvc_scale_act_res: bad y2");
+  const long total = (long)a->N * a->H * a->W * ((a->C + 7) / 8);
+  hipLaunchKernelGGL(scale_act_res_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*a), gate, act, slope,
+                     r ? to_dev(*r) : null_fmap(), r_sign, to_dev(*y), y2 ? to_dev(*y2) : null_fmap());
+  return tdvc_launch_status("tdvc_scale_act_res");
+}
+
+extern "C" int tdvc_add_flow(const tdvc_fmap* off, const tdvc_fmap* flow, void* stream) {
+  TDVC_CHECK(off && flow && fmap_ok16(*off) && fmap_ok32(*flow) && flow->C >= 2 && same_geom(*off, *flow), "tdvc_add_flow: bad arguments");
+  const long total = (long)off->N * off->H * off->W * (off->C / 8);
+  hipLaunchKernelGGL(add_flow_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*off), to_dev(*flow));
+  return tdvc_launch_status("tdvc_add_flow");
+}
+
+extern "C" int tdvc_bcast_add_act(const tdvc_fmap* x, const tdvc_fmap* b, int T, float slope, void* stream) {
+  TDVC_CHECK(x && b && fmap_ok16(*x) && fmap_ok16(*b) && same_geom(*x, *b) && x->C == T * b->C, "tdvc_bcast_add_act: bad arguments");
+  const long total = (long)x->N * x->H * x->W * (x->C / 8);
+  hipLaunchKernelGGL(bcast_add_act_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*x), to_dev(*b), slope);
+  return tdvc_launch_status("tdvc_bcast_add_act");
+}
+
+extern "C" int tdvc_channel_sum(const tdvc_fmap* x, float* partial, int nblocks, void* stream) {
+  TDVC_CHECK(x && partial && fmap_ok16(*x) && x->C <= 256 && nblocks >= 1 && nblocks <= 4096, "tdvc_channel_sum: bad arguments");
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(nblocks, x->N), dim3(256), 0, ST(stream), to_dev(*x), partial, nblocks);
+  return tdvc_launch_status("tdvc_channel_sum");
+}
+
+extern "C" int tdvc_se_gate(const float* partial, int nblocks, float inv_count, int N, int C, int Cmid,
+                            const float* w1, const float* b1, const float* w2, const float* b2, float* gate, void* stream) {
+  TDVC_CHECK(partial && w1 && b1 && w2 && b2 && gate && C <= 256 && Cmid <= 32 && N >= 1, "tdvc_se_gate: bad arguments");
+  hipLaunchKernelGGL(se_gate_kernel, dim3(N), dim3(256), 0, ST(stream), partial, nblocks, inv_count, C, Cmid, w1, b1, w2, b2, gate);
+  return tdvc_launch_status("tdvc_se_gate");
+}
+
+extern "C" int tdvc_upsample2x(const tdvc_fmap* x, const tdvc_fmap* y, void* stream) {
+  TDVC_CHECK(x && y && fmap_ok16(*x) && fmap_ok16(*y) && y->H == 2 * x->H && y->W == 2 * x->W && y->C == x->C && y->N == x->N,
+             "tdvc_upsample2x: bad arguments");
+  const long total = (long)y->N * y->H * y->W * (y->C / 8);
+  hipLaunchKernelGGL(upsample2x_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*x), to_dev(*y));
+  return tdvc_launch_status("tdvc_upsample2x");
+}
+
+extern "C" int tdvc_avgpool2(const tdvc_fmap* x, const tdvc_fmap* y, void* stream) {
+  TDVC_CHECK(x && y && fmap_ok32(*x) && fmap_ok32(*y) && y->H == x->H / 2 && y->W == x->W / 2 && y->C <= x->C && y->N == x->N,
+             "tdvc_avgpool2: bad arguments");
+  const long total = (long)y->N * y->H * y->W;
+  hipLaunchKernelGGL(avgpool2_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*x), to_dev(*y));
+  return tdvc_launch_status("tdvc_avgpool2");
+}
+
+extern "C" int tdvc_spynet_level_input(const tdvc_fmap* ref, const tdvc_fmap* supp, const tdvc_fmap* flow_lo,
+                                       const tdvc_fmap* flow_up, const tdvc_fmap* cat8, void* stream) {
+  TDVC_CHECK(ref && supp && flow_up && cat8, "tdvc_spynet_level_input: null");
+  TDVC_CHECK(fmap_ok32(*ref) && fmap_ok32(*supp) && ref->C >= 3 && supp->C >= 3 && same_geom(*ref, *supp), "tdvc_spynet_level_input: bad ref/supp");
+  TDVC_CHECK(fmap_ok32(*flow_up) && flow_up->C >= 2 && same_geom(*ref, *flow_up), "tdvc_spynet_level_input: bad flow_up");
+  TDVC_CHECK(fmap_ok16(*cat8) && cat8->C == 8 && same_geom(*ref, *cat8), "tdvc_spynet_level_input: bad cat8");
+  if (flow_lo) TDVC_CHECK(fmap_ok32(*flow_lo) && flow_lo->C >= 2 && flow_lo->N == ref->N && flow_lo->H * 2 == ref->H && flow_lo->W * 2 == ref->W,
+                          "tdvc_spynet_level_input: bad flow_lo");
+  const long total = (long)ref->N * ref->H * ref->W;
+  hipLaunchKernelGGL(spynet_level_input_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*ref), to_dev(*supp),
+                     flow_lo ? to_dev(*flow_lo) : null_fmap(), to_dev(*flow_up), to_dev(*cat8));
+  return tdvc_launch_status("tdvc_spynet_level_input");
+}
+
+extern "C" int tdvc_resize_bilinear(const tdvc_fmap* x, const tdvc_fmap* y, const float* chscale, void* stream) {
+  TDVC_CHECK(x && y && fmap_ok32(*x) && fmap_ok32(*y) && y->C <= x->C && y->N == x->N, "tdvc_resize_bilinear: bad arguments");
+  const long total = (long)y->N * y->H * y->W;
+  hipLaunchKernelGGL(resize_bilinear_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*x), to_dev(*y), chscale);
+  return tdvc_launch_status("tdvc_resize_bilinear");
+}
+
+extern "C" int tdvc_avgpool_k(const tdvc_fmap* x, int scale, float* pooled, int hp, int wp, void* stream) {
+  TDVC_CHECK(x && pooled && fmap_ok16(*x) && x->C <= 256 && scale >= 1 && hp == x->H / scale && wp == x->W / scale && hp >= 1 && wp >= 1,
+             "tdvc_avgpool_k: bad arguments");
+  hipLaunchKernelGGL(avgpool_k_kernel, dim3(hp * wp, x->N), dim3(256), 0, ST(stream), to_dev(*x), scale, pooled, hp, wp);
+  return tdvc_launch_status("tdvc_avgpool_k");
+}
+
+extern "C" int tdvc_patch_match(const float* pin, const float* pref, int N, int hp, int wp, int C, int32_t* idx, void* stream) {
+  TDVC_CHECK(pin && pref && idx && N >= 1 && hp >= 1 && wp >= 1 && C >= 1 && C * 9 * 4 <= 60000, "tdvc_patch_match: bad arguments");
+  const int nph = (hp + 3) / 3 + 1, npw = (wp + 3) / 3 + 1;
+  hipLaunchKernelGGL(patch_match_kernel, dim3(nph * npw, N), dim3(256), (size_t)C * 9 * 4, ST(stream), pin, pref, hp, wp, C, nph, npw, idx);
+  return tdvc_launch_status("tdvc_patch_match");
+}
+
+extern "C" int tdvc_match_gather(const tdvc_fmap* fin, const tdvc_fmap* fref, const int32_t* idx, int scale, int hp, int wp,
+                                 const tdvc_fmap* cat, void* stream) {
+  TDVC_CHECK(fin && fref && idx && cat && fmap_ok16(*fin) && fmap_ok16(*fref) && fmap_ok16(*cat), "tdvc_match_gather: bad fmaps");
+  TDVC_CHECK(fin->C == 64 && fref->C == 64 && cat->C == 128 && same_geom(*fin, *fref) && same_geom(*fin, *cat), "tdvc_match_gather: needs C=64 / cat C=128");
+  const int ks = 3 * scale;
+  const int nbh = (fin->H + ks) / ks + 1, nbw = (fin->W + ks) / ks + 1;   // fold(kernel=ks, pad=ks, stride=ks)
+  TDVC_CHECK(nbh == (hp + 3) / 3 + 1 && nbw == (wp + 3) / 3 + 1,
+             "tdvc_match_gather: fold grid %dx%d != patch grid %dx%d (F.fold would raise, pnet.py:252)", nbh, nbw, (hp + 3) / 3 + 1, (wp + 3) / 3 + 1);
+  const long total = (long)fin->N * fin->H * fin->W * 8;
+  hipLaunchKernelGGL(match_gather_kernel, grid1d(total), dim3(256), 0, ST(stream), to_dev(*fin), to_dev(*fref), idx, ks, nbh, nbw, to_dev(*cat));
+  return tdvc_launch_status("tdvc_match_gather");
+}
+
+extern "C" int tdvc_eb_forward(const tdvc_fmap* z, const float* params, const tdvc_fmap* noise,
+                               const tdvc_fmap* z_hat, double* bits_out, float* partial, int partial_cap, void* stream) {
+  TDVC_CHECK(z && params && z_hat && bits_out && partial && fmap_ok32(*z) && fmap_any(*z_hat) && same_geom(*z, *z_hat) && z_hat->C >= z->C,
+             "tdvc_eb_forward: bad arguments");
+  if (noise) TDVC_CHECK(fmap_ok32(*noise) && same_geom(*z, *noise) && noise->C >= z->C, "tdvc_eb_forward: bad noise");
+  const long total = (long)z->N * z->H * z->W * z->C;
+  const int nb = (int)((total + 255) / 256);
+  TDVC_CHECK(nb <= partial_cap, "tdvc_eb_forward: partial buffer too small (%d < %d)", partial_cap, nb);
+  hipLaunchKernelGGL(eb_forward_kernel, dim3(nb), dim3(256), 0, ST(stream), to_dev(*z), params, noise ? to_dev(*noise) : null_fmap(), to_dev(*z_hat), partial);
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, ST(stream), partial, nb, bits_out);
+  return tdvc_launch_status("tdvc_eb_forward");
+}
+
+extern "C" int tdvc_gc_forward(const tdvc_fmap* y, const tdvc_fmap* gp, const tdvc_fmap* noise,
+                               double* bits_out, float* partial, int partial_cap, void* stream) {
+  TDVC_CHECK(y && gp && bits_out && partial && fmap_ok32(*y) && fmap_ok32(*gp) && same_geom(*y, *gp) && gp->C >= 2 * y->C, "tdvc_gc_forward: bad arguments");
+  if (noise) TDVC_CHECK(fmap_ok32(*noise) && same_geom(*y, *noise) && noise->C >= y->C, "tdvc_gc_forward: bad noise");
+  const long total = (long)y->N * y->H * y->W * y->C;
+  const int nb = (int)((total + 255) / 256);
+  TDVC_CHECK(nb <= partial_cap, "tdvc_gc_forward: partial buffer too small (%d < %d)", partial_cap, nb);
+  hipLaunchKernelGGL(gc_forward_kernel, dim3(nb), dim3(256), 0, ST(stream), to_dev(*y), to_dev(*gp), noise ? to_dev(*noise) : null_fmap(), partial);
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, ST(stream), partial, nb, bits_out);
+  return tdvc_launch_status("tdvc_gc_forward");
+}
+
+extern "C" int tdvc_quantize(const tdvc_fmap* y, const tdvc_fmap* noise, const tdvc_fmap* y_hat, void* stream) {
+  TDVC_CHECK(y && y_hat && fmap_any(*y) && fmap_any(*y_hat) && same_geom(*y, *y_hat) && y_hat->C >= y->C, "tdvc_quantize: bad arguments");
+  if (noise) TDVC_CHECK(fmap_any(*noise) && same_geom(*y, *noise) && noise->C >= y->C, "tdvc_quantize: bad noise");
+  const long total = (long)y->N * y->H * y->W * ((y->C + 7) / 8);
+  hipLaunchKernelGGL(quantize_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*y), noise ? to_dev(*noise) : null_fmap(), to_dev(*y_hat));
+  return tdvc_launch_status("tdvc_quantize");
+}

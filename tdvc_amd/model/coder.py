@@ -1,0 +1,339 @@
+"""Motion / residual auto-encoders with hyperprior + context entropy model, MI355X-native.
+
+Parameter layout mirrors `MVCoder` / `ResCoder` of `main/model/encoder_v3.py:14-69`, i.e.
+CompressAI's `Cheng2020Anchor(N=128)` with g_a/g_s replaced (state-dict names of CompressAI
+1.1.x; compressai itself is not a dependency).  All transforms run through the MFMA conv
+kernel; GDN is the same kernel with a squared-input prologue and a `x * rsqrt(.)` epilogue;
+PixelShuffle is a store pattern; the rate terms are fused elementwise kernels.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..ops import ACT_LRELU, ACT_NONE, FM, GDN_FWD, GDN_INV
+from .modules import PackCache, SELayer, pk_conv
+
+
+# ------------------------------------------------------------------ parameter holders
+class LowerBound(nn.Module):
+    def __init__(self, bound):
+        super().__init__()
+        self.register_buffer("bound", torch.Tensor([float(bound)]))
+
+
+class NonNegativeParametrizer(nn.Module):
+    def __init__(self, minimum=0.0, reparam_offset=2 ** -18):
+        super().__init__()
+        ped = float(reparam_offset) ** 2
+        self.register_buffer("pedestal", torch.Tensor([ped]))
+        self.lower_bound = LowerBound((float(minimum) + ped) ** 0.5)
+
+    def init(self, x):
+        return torch.sqrt(torch.max(x + self.pedestal, self.pedestal))
+
+    def effective(self, x):
+        return torch.max(x, self.lower_bound.bound) ** 2 - self.pedestal
+
+
+class GDN(nn.Module, PackCache):
+    def __init__(self, ch, inverse=False, beta_min=1e-6, gamma_init=0.1):
+        super().__init__()
+        self.inverse = bool(inverse)
+        self.beta_reparam = NonNegativeParametrizer(minimum=beta_min)
+        self.beta = nn.Parameter(self.beta_reparam.init(torch.ones(ch)))
+        self.gamma_reparam = NonNegativeParametrizer()
+        self.gamma = nn.Parameter(self.gamma_reparam.init(gamma_init * torch.eye(ch)))
+
+    def run(self, x: FM, out: FM | None = None, res: FM | None = None) -> FM:
+        """out = x * (r)sqrt(beta + gamma @ x^2) + res"""
+        def build():
+            g = self.gamma_reparam.effective(self.gamma.detach())
+            b = self.beta_reparam.effective(self.beta.detach())
+            c = g.shape[0]
+            return ops.pack_conv(g.reshape(c, c, 1, 1), b, stride=1, pad=0, device=self.gamma.device)
+        pc = self._pk("gdn", build)
+        return ops.conv(x, pc, out=out, square=True, gdn=GDN_INV if self.inverse else GDN_FWD, aux=x, res=res)
+
+
+def conv3x3(cin, cout, stride=1):
+    return nn.Conv2d(cin, cout, 3, stride, 1)
+
+
+def conv1x1(cin, cout, stride=1):
+    return nn.Conv2d(cin, cout, 1, stride)
+
+
+def subpel_conv3x3(cin, cout, r=1):
+    return nn.Sequential(nn.Conv2d(cin, cout * r ** 2, 3, padding=1), nn.PixelShuffle(r))
+
+
+LR = dict(act=ACT_LRELU, slope=0.01)
+
+
+class ResidualBlock(nn.Module, PackCache):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1 = conv3x3(cin, cout)
+        self.conv2 = conv3x3(cout, cout)
+        self.skip = conv1x1(cin, cout) if cin != cout else None
+
+    def run(self, x: FM, out: FM | None = None) -> FM:
+        t = ops.conv(x, pk_conv(self, "c1", self.conv1), **LR)
+        idt = x if self.skip is None else ops.conv(x, pk_conv(self, "sk", self.skip))
+        return ops.conv(t, pk_conv(self, "c2", self.conv2), out=out, res=idt, **LR)
+
+
+class ResidualBlockWithStride(nn.Module, PackCache):
+    def __init__(self, cin, cout, stride=2):
+        super().__init__()
+        self.conv1 = conv3x3(cin, cout, stride)
+        self.conv2 = conv3x3(cout, cout)
+        self.gdn = GDN(cout)
+        self.skip = conv1x1(cin, cout, stride) if (stride != 1 or cin != cout) else None
+
+    def run(self, x: FM, out: FM | None = None) -> FM:
+        t = ops.conv(x, pk_conv(self, "c1", self.conv1), **LR)
+        t = ops.conv(t, pk_conv(self, "c2", self.conv2))
+        idt = x if self.skip is None else ops.conv(x, pk_conv(self, "sk", self.skip))
+        return self.gdn.run(t, out=out, res=idt)
+
+
+class ResidualBlockUpsample(nn.Module, PackCache):
+    def __init__(self, cin, cout, upsample=2):
+        super().__init__()
+        assert upsample == 2
+        self.subpel_conv = subpel_conv3x3(cin, cout, upsample)
+        self.conv = conv3x3(cout, cout)
+        self.igdn = GDN(cout, inverse=True)
+        self.upsample = subpel_conv3x3(cin, cout, upsample)
+
+    def run(self, x: FM, out: FM | None = None) -> FM:
+        t = ops.conv(x, pk_conv(self, "sp", self.subpel_conv[0], shuffle=True), **LR)
+        t = ops.conv(t, pk_conv(self, "c", self.conv))
+        up = ops.conv(x, pk_conv(self, "up", self.upsample[0], shuffle=True))
+        return self.igdn.run(t, out=out, res=up)
+
+
+class MaskedConv2d(nn.Conv2d):
+    """type-A mask buffer kept for state-dict compatibility; masked taps are dropped at pack time"""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.register_buffer("mask", torch.ones_like(self.weight.data))
+        _, _, h, w = self.mask.shape
+        self.mask[:, :, h // 2, w // 2:] = 0
+        self.mask[:, :, h // 2 + 1:] = 0
+
+    def live_taps(self):
+        h, w = self.kernel_size
+        return [(dy, dx) for dy in range(h) for dx in range(w) if dy < h // 2 or (dy == h // 2 and dx < w // 2)]
+
+
+class EntropyBottleneck(nn.Module, PackCache):
+    """factorised prior parameters (CompressAI 1.1.x names)"""
+
+    def __init__(self, channels, tail_mass=1e-9, init_scale=10, filters=(3, 3, 3, 3), likelihood_bound=1e-9):
+        super().__init__()
+        self.channels = int(channels)
+        self.filters = tuple(int(f) for f in filters)
+        self.init_scale = float(init_scale)
+        self.tail_mass = float(tail_mass)
+        self.likelihood_lower_bound = LowerBound(likelihood_bound)
+        self.register_buffer("_offset", torch.IntTensor())
+        self.register_buffer("_quantized_cdf", torch.IntTensor())
+        self.register_buffer("_cdf_length", torch.IntTensor())
+        f = (1,) + self.filters + (1,)
+        scale = self.init_scale ** (1 / (len(self.filters) + 1))
+        for i in range(len(self.filters) + 1):
+            init = np.log(np.expm1(1 / scale / f[i + 1]))
+            self.register_parameter(f"_matrix{i:d}", nn.Parameter(torch.full((channels, f[i + 1], f[i]), float(init))))
+            self.register_parameter(f"_bias{i:d}", nn.Parameter(torch.zeros(channels, f[i + 1], 1).uniform_(-0.5, 0.5)))
+            if i < len(self.filters):
+                self.register_parameter(f"_factor{i:d}", nn.Parameter(torch.zeros(channels, f[i + 1], 1)))
+        q = torch.Tensor([-self.init_scale, 0, self.init_scale])
+        self.quantiles = nn.Parameter(q.repeat(channels, 1, 1))
+        self.register_buffer("target", torch.Tensor([np.log(2 / self.tail_mass - 1)]))
+
+    def packed_params(self) -> torch.Tensor:
+        """[C][59] fp32: softplus(matrix0..4) | bias0..4 | tanh(factor0..3) | median"""
+        def build():
+            C_ = self.channels
+            parts = [F.softplus(getattr(self, f"_matrix{i}").detach()).reshape(C_, -1) for i in range(5)]
+            parts += [getattr(self, f"_bias{i}").detach().reshape(C_, -1) for i in range(5)]
+            parts += [torch.tanh(getattr(self, f"_factor{i}").detach()).reshape(C_, -1) for i in range(4)]
+            parts += [self.quantiles.detach()[:, 0, 1:2]]
+            p = torch.cat(parts, 1).float().contiguous()
+            assert p.shape == (C_, 59)
+            return p
+        return self._pk("eb", build)
+
+    def logits_cumulative(self, x, stop_gradient):
+        for i in range(len(self.filters) + 1):
+            m, b = getattr(self, f"_matrix{i:d}"), getattr(self, f"_bias{i:d}")
+            if stop_gradient:
+                m, b = m.detach(), b.detach()
+            x = torch.matmul(F.softplus(m), x) + b
+            if i < len(self.filters):
+                fac = getattr(self, f"_factor{i:d}")
+                if stop_gradient:
+                    fac = fac.detach()
+                x = x + torch.tanh(fac) * torch.tanh(x)
+        return x
+
+    def loss(self):
+        """aux loss on the 3 quantiles per channel (parameter space, 128x3 values) — plain autograd"""
+        logits = self.logits_cumulative(self.quantiles, stop_gradient=True)
+        return torch.abs(logits - self.target).sum()
+
+
+class GaussianConditional(nn.Module):
+    def __init__(self, scale_bound=0.11, tail_mass=1e-9, likelihood_bound=1e-9):
+        super().__init__()
+        self.tail_mass = float(tail_mass)
+        self.likelihood_lower_bound = LowerBound(likelihood_bound)
+        self.register_buffer("_offset", torch.IntTensor())
+        self.register_buffer("_quantized_cdf", torch.IntTensor())
+        self.register_buffer("_cdf_length", torch.IntTensor())
+        self.register_buffer("scale_table", torch.Tensor())
+        self.lower_bound_scale = LowerBound(scale_bound)
+
+
+# ------------------------------------------------------------------ the coder
+class Cheng2020Anchor(nn.Module, PackCache):
+    def __init__(self, N=192):
+        super().__init__()
+        self.N = self.M = M = N
+        self.entropy_bottleneck = EntropyBottleneck(N)
+        self.h_a = nn.Sequential(
+            conv3x3(N, N), nn.LeakyReLU(inplace=True), conv3x3(N, N), nn.LeakyReLU(inplace=True),
+            conv3x3(N, N, stride=2), nn.LeakyReLU(inplace=True), conv3x3(N, N), nn.LeakyReLU(inplace=True),
+            conv3x3(N, N, stride=2))
+        self.h_s = nn.Sequential(
+            conv3x3(N, N), nn.LeakyReLU(inplace=True), subpel_conv3x3(N, N, 2), nn.LeakyReLU(inplace=True),
+            conv3x3(N, N * 3 // 2), nn.LeakyReLU(inplace=True), subpel_conv3x3(N * 3 // 2, N * 3 // 2, 2),
+            nn.LeakyReLU(inplace=True), conv3x3(N * 3 // 2, N * 2))
+        self.entropy_parameters = nn.Sequential(
+            nn.Conv2d(M * 12 // 3, M * 10 // 3, 1), nn.LeakyReLU(inplace=True),
+            nn.Conv2d(M * 10 // 3, M * 8 // 3, 1), nn.LeakyReLU(inplace=True),
+            nn.Conv2d(M * 8 // 3, M * 6 // 3, 1))
+        self.context_prediction = MaskedConv2d(M, 2 * M, kernel_size=5, padding=2, stride=1)
+        self.gaussian_conditional = GaussianConditional()
+
+    # -- transforms ------------------------------------------------------------------------
+    def run_g_a(self, x: FM):
+        """-> (y fp32 FM, y fp16 FM)"""
+        g = self.g_a
+        t = g[0].run(x)
+        t = g[1].run(t)
+        t = g[2].run(t)
+        t = g[3].run(t)            # SE
+        t = g[4].run(t)
+        t = g[5].run(t)
+        t = g[6].run(t)
+        t = ops.conv(t, pk_conv(self, "ga7", g[7]))
+        y32 = FM.empty(t.N, t.H, t.W, t.C, dtype=torch.float32, device=t.t.device)
+        y16 = FM.empty(t.N, t.H, t.W, t.C, device=t.t.device)
+        g[8].run(t, out=y32, out2=y16)
+        return y32, y16
+
+    def run_g_s(self, y_hat: FM, out: FM | None = None, res: FM | None = None) -> FM:
+        g = self.g_s
+        t = g[0].run(y_hat)
+        for i in range(1, 5):
+            t = g[i].run(t)
+        t = g[5].run(t)
+        for i in range(6, 9):
+            t = g[i].run(t)
+        return ops.conv(t, pk_conv(self, "gs9", g[9][0], shuffle=True), out=out, res=res)
+
+    def run_h_a(self, y16: FM) -> FM:
+        h = self.h_a
+        t = ops.conv(y16, pk_conv(self, "ha0", h[0]), **LR)
+        t = ops.conv(t, pk_conv(self, "ha2", h[2]), **LR)
+        t = ops.conv(t, pk_conv(self, "ha4", h[4]), **LR)
+        t = ops.conv(t, pk_conv(self, "ha6", h[6]), **LR)
+        return ops.conv(t, pk_conv(self, "ha8", h[8]), out_dtype=torch.float32)
+
+    def run_h_s(self, z_hat: FM, out: FM) -> FM:
+        h = self.h_s
+        t = ops.conv(z_hat, pk_conv(self, "hs0", h[0]), **LR)
+        t = ops.conv(t, pk_conv(self, "hs2", h[2][0], shuffle=True), **LR)
+        t = ops.conv(t, pk_conv(self, "hs4", h[4]), **LR)
+        t = ops.conv(t, pk_conv(self, "hs6", h[6][0], shuffle=True), **LR)
+        return ops.conv(t, pk_conv(self, "hs8", h[8]), out=out)
+
+    def run_entropy_parameters(self, pc_in: FM) -> FM:
+        e = self.entropy_parameters
+        t = ops.conv(pc_in, pk_conv(self, "ep0", e[0]), **LR)
+        t = ops.conv(t, pk_conv(self, "ep2", e[2]), **LR)
+        return ops.conv(t, pk_conv(self, "ep4", e[4]), out_dtype=torch.float32)
+
+    def ctx_conv(self) -> ops.PackedConv:
+        cp = self.context_prediction
+        return self._pk("ctx", lambda: ops.pack_conv(cp.weight, cp.bias, stride=1, pad=2, taps=cp.live_taps(),
+                                                     device=cp.weight.device))
+
+    # -- forward (`main/model/pnet.py:34,58`) ------------------------------------------------
+    def run(self, x: FM, training: bool, out: FM | None = None, res: FM | None = None, trace=None):
+        """x: (B,H,W,64) fp16.  Returns (x_hat FM [+res], bits tensor (2,) float64 = [y, z])."""
+        dev = x.t.device
+        y32, y16 = self.run_g_a(x)
+        z = self.run_h_a(y16)
+        B, h, w, M = y32.N, y32.H, y32.W, self.M
+        bits = torch.zeros(2, dtype=torch.float64, device=dev)
+        z_hat = FM.empty(z.N, z.H, z.W, z.C, device=dev)
+        nz = ny = None
+        if training:
+            nz = FM(torch.rand((z.N, z.H, z.W, z.C), device=dev) - 0.5)
+            ny = FM(torch.rand((B, h, w, M), device=dev) - 0.5)
+        ops.eb_forward(z, self.entropy_bottleneck.packed_params(), z_hat, bits[1:2], noise=nz)
+        pcat = FM.empty(B, h, w, 4 * M, device=dev)             # [h_s params | context]
+        self.run_h_s(z_hat, out=pcat.ch(0, 2 * M))
+        y_hat = ops.quantize(y32, FM.empty(B, h, w, M, device=dev), noise=ny)
+        ops.conv(y_hat, self.ctx_conv(), out=pcat.ch(2 * M, 2 * M))
+        gp = self.run_entropy_parameters(pcat)
+        ops.gc_forward(y32, gp, bits[0:1], noise=ny)
+        x_hat = self.run_g_s(y_hat, out=out, res=res)
+        if trace is not None:
+            trace.update(y=y32, z=z, z_hat=z_hat, y_hat=y_hat, gp=gp)
+        return x_hat, bits
+
+    def aux_loss(self):
+        return self.entropy_bottleneck.loss()
+
+
+def _g_a(N):
+    return nn.Sequential(
+        ResidualBlockWithStride(64, N, stride=2), ResidualBlock(N, N),
+        ResidualBlockWithStride(N, N, stride=2), SELayer(N), ResidualBlock(N, N),
+        ResidualBlockWithStride(N, N, stride=2), ResidualBlock(N, N),
+        conv3x3(N, N, stride=2), SELayer(N))
+
+
+def _g_s(N):
+    return nn.Sequential(
+        SELayer(N), ResidualBlock(N, N), ResidualBlockUpsample(N, N, 2), ResidualBlock(N, N),
+        ResidualBlockUpsample(N, N, 2), SELayer(N), ResidualBlock(N, N),
+        ResidualBlockUpsample(N, N, 2), ResidualBlock(N, N), subpel_conv3x3(N, 64, 2))
+
+
+class ResCoder(Cheng2020Anchor):
+    """`main/model/encoder_v3.py:14-40`"""
+
+    def __init__(self, N=192):
+        super().__init__(N=N)
+        self.g_a, self.g_s = _g_a(N), _g_s(N)
+
+
+class MVCoder(Cheng2020Anchor):
+    """`main/model/encoder_v3.py:43-69`"""
+
+    def __init__(self, N=192):
+        super().__init__(N=N)
+        self.g_a, self.g_s = _g_a(N), _g_s(N)

@@ -1,0 +1,93 @@
+"""`VideoCompressor` — drop-in for `main/model/pnet.py:15-83` on MI355X.
+
+Same constructor (no arguments), same `forward(input_image, refer_frames, enabled_amp,
+is_compress=False)` signature and return tuple, same state-dict keys (`mvCoder, resCoder,
+extra_fea, motion_est, mcnet, loopfilter, mcfilter`).  The whole forward runs in hand-written
+gfx950 kernels (libtdvc_hip.so): fp16 NHWC activations with fp32 accumulation for every conv
+(the reference under AMP computes its convs in fp16 too, and keeps the two coders in fp32 —
+here they are fp16-in / fp32-accumulate as well), fp32 for flow, SE gates,
+matching and rate terms.  There is no PyTorch/CPU fallback: tensors must live on a HIP device.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import FM
+from .coder import MVCoder, ResCoder
+from .modules import FeaExtra, FeatureFix, LoopFilter, MCNet, OffsetGen
+
+
+class VideoCompressor(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.mvCoder = MVCoder(N=128)
+        self.resCoder = ResCoder(N=128)
+        self.extra_fea = FeaExtra(2)
+        self.motion_est = OffsetGen()
+        self.mcnet = MCNet(3)
+        self.loopfilter = FeatureFix()      # reference-based in-loop filter (sic, pnet.py:23)
+        self.mcfilter = LoopFilter()        # multi-frame feature fusion (sic, pnet.py:24)
+
+    # packed-weight cache -------------------------------------------------------------------
+    def clear_packed(self):
+        for m in self.modules():
+            m.__dict__.pop("_packed", None)
+
+    def load_state_dict(self, *a, **kw):
+        r = super().load_state_dict(*a, **kw)
+        self.clear_packed()
+        return r
+
+    def _apply(self, fn, *a, **kw):
+        self.clear_packed()
+        return super()._apply(fn, *a, **kw)
+
+    # ----------------------------------------------------------------------------------------
+    def forward(self, input_image, refer_frames, enabled_amp=True, is_compress=False, trace=None):
+        if not (input_image.is_cuda and refer_frames.is_cuda):
+            raise RuntimeError("tdvc_amd.VideoCompressor runs on a HIP device only (no CPU fallback)")
+        if self.training:
+            raise NotImplementedError("training-mode forward (noise quantisation + autograd) lands with the backward kernels")
+        B, _, H, W = input_image.shape
+        if H % 64 or W % 64:
+            raise RuntimeError(f"input must be padded to a multiple of 64 (got {H}x{W}); see tools/predict.py:51-53")
+        dev = input_image.device
+        with torch.cuda.device(dev), torch.no_grad():
+            x = input_image.float()
+            refs = refer_frames.float().reshape(B * 4, 3, H, W)
+            cur32 = ops.from_nchw(x, Cpad=4, dtype=torch.float32)
+            cur8 = ops.from_nchw(x, Cpad=8)
+            refs8 = ops.from_nchw(refs, Cpad=8)                          # (B*4,H,W,8): [I, r-3, r-2, r-1]
+            last = refer_frames[:, 3].float()
+            ref32 = ops.from_nchw(last, Cpad=4, dtype=torch.float32)
+            ref8 = ops.from_nchw(last, Cpad=8)
+            iframe8 = ops.from_nchw(refer_frames[:, 0].float(), Cpad=8)
+
+            feats = FM.empty(B, H, W, 192, device=dev)                   # [f_cur | f_ref | dcn_out]
+            f_cur = self.extra_fea.run(cur8, feats.ch(0, 64))
+            self.extra_fea.run(ref8, feats.ch(64, 64))
+            estmv = self.motion_est.run(feats, cur32, ref32)
+
+            tr_mv = {} if trace is not None else None
+            mv_hat, mv_bits = self.mvCoder.run(estmv, training=False, trace=tr_mv)
+
+            xt = FM.empty(B, H, W, 256, device=dev)                      # 4 frames x 64 ch
+            pred1 = self.mcnet.run(mv_hat, feats, xt.ch(192, 64))
+            pred = FM.empty(B, H, W, 64, device=dev)
+            self.mcfilter.run(xt, refs8, pred)
+            resid = ops.scale_act_res(f_cur, FM.empty(B, H, W, 64, device=dev), res=pred, res_sign=-1.0)
+
+            tr_res = {} if trace is not None else None
+            recon_f, res_bits = self.resCoder.run(resid, training=False, res=pred, trace=tr_res)
+
+            recon = self.loopfilter.run(recon_f, iframe8, training=False, trace=trace)
+
+            npx = float(B * H * W)
+            bpp_mv = (mv_bits.sum() / npx).float().view(-1)
+            bpp_res = (res_bits.sum() / npx).float().view(-1)
+            if trace is not None:
+                trace.update(f_cur=f_cur, f_ref=feats.ch(64, 64), estmv=estmv, mv_x_hat=mv_hat, pred1=pred1, pred=pred,
+                             resid=resid, recon_f=recon_f, mv=tr_mv, res=tr_res)
+        return recon, bpp_res, bpp_mv

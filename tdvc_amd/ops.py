@@ -1,0 +1,358 @@
+"""Host-side operator layer: torch tensors (device memory + streams only) -> C-ABI calls.
+
+`FM` is a channel-innermost feature-map view ([N][H][W][C], fp16 or fp32) over a torch buffer;
+channel slices of a wider buffer are views, so concatenations are never materialised.
+Every function enqueues on torch's current HIP stream and returns immediately.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from ._lib import (ACT_CLAMP01, ACT_LRELU, ACT_NONE, ACT_RELU, GDN_FWD, GDN_INV, GDN_NONE, OUT_NCHW_F32,  # noqa: F401
+                   OUT_NHWC, OUT_SHUFFLE2)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def pad8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+class FM:
+    """Feature-map view over a torch buffer `t` of shape (N, H, W, Cbuf): N images of C channels
+    starting `off` elements into the buffer, batch stride `sn`, pixel stride t.stride(2)."""
+
+    __slots__ = ("t", "off", "N", "C", "H", "W", "sn")
+
+    def __init__(self, t: torch.Tensor, off: int = 0, N: int | None = None, C_: int | None = None, sn: int | None = None):
+        assert t.dim() == 4 and t.stride(3) == 1 and t.stride(1) == t.shape[2] * t.stride(2)
+        self.t, self.off = t, off
+        self.N = t.shape[0] if N is None else N
+        self.C = t.shape[3] if C_ is None else C_
+        self.H, self.W = t.shape[1], t.shape[2]
+        self.sn = t.stride(0) if sn is None else sn
+
+    @staticmethod
+    def empty(N, H, W, C_, dtype=torch.float16, device="cuda"):
+        return FM(torch.empty((N, H, W, C_), dtype=dtype, device=device))
+
+    @staticmethod
+    def zeros(N, H, W, C_, dtype=torch.float16, device="cuda"):
+        return FM(torch.zeros((N, H, W, C_), dtype=dtype, device=device))
+
+    @property
+    def f32(self):
+        return self.t.dtype == torch.float32
+
+    def ch(self, c0, C_):
+        """channel slice view"""
+        assert 0 <= c0 and c0 + C_ <= self.C
+        return FM(self.t, self.off + c0, self.N, C_, self.sn)
+
+    def batch(self, n0, N):
+        assert 0 <= n0 and n0 + N <= self.N
+        return FM(self.t, self.off + n0 * self.sn, N, self.C, self.sn)
+
+    def as_slices(self, b, T, Cs):
+        """the T channel-slices (width Cs) of batch item b, viewed as a batch of T images"""
+        assert self.C == T * Cs and 0 <= b < self.N
+        return FM(self.t, self.off + b * self.sn, T, Cs, Cs)
+
+    def desc(self) -> L.FMapDesc:
+        p = self.t.data_ptr() + self.off * self.t.element_size()
+        return L.FMapDesc(p, self.N, self.H, self.W, self.C, self.sn, self.t.stride(2),
+                          L.F32 if self.f32 else L.F16)
+
+    def to_nchw(self, C_=None) -> torch.Tensor:
+        C_ = self.C if C_ is None else C_
+        out = torch.empty((self.N, C_, self.H, self.W), dtype=torch.float32, device=self.t.device)
+        d = self.desc()
+        L.check(L.lib().tdvc_fmap_to_nchw(C.byref(d), C_, out.data_ptr(), _stream()), "fmap_to_nchw")
+        return out
+
+
+_NULL_FM = L.FMapDesc(None, 0, 0, 0, 0, 0, 0, 0)
+
+
+def from_nchw(x: torch.Tensor, Cpad: int | None = None, dtype=torch.float16, out: FM | None = None) -> FM:
+    """(N,C,H,W) fp32 cuda tensor -> FM (channels zero-padded to Cpad)."""
+    assert x.is_cuda and x.dtype == torch.float32
+    x = x.contiguous()
+    N, Cc, H, W = x.shape
+    if out is None:
+        out = FM.empty(N, H, W, pad8(Cc) if Cpad is None else Cpad, dtype=dtype, device=x.device)
+    d = out.desc()
+    L.check(L.lib().tdvc_nchw_to_fmap(x.data_ptr(), Cc, C.byref(d), _stream()), "nchw_to_fmap")
+    return out
+
+
+# ----------------------------------------------------------------------------- conv
+@dataclass
+class PackedConv:
+    w: torch.Tensor          # device uint8 blob (fragment-ordered fp16)
+    bias: torch.Tensor       # device fp32 [cout_pad]
+    cout: int
+    cin: int                 # padded input channels the kernel will see
+    kh: int
+    kw: int
+    stride: int
+    pad: int
+    ck: int
+    taps: list               # [(dy, dx)]
+    shuffle: bool = False
+
+
+def _cout_pad(cout):
+    return 32 if cout <= 32 else 64 * ((cout + 63) // 64)
+
+
+def pack_conv(weight: torch.Tensor, bias: torch.Tensor | None, stride=1, pad=0, cin_pad: int | None = None,
+              taps=None, shuffle=False, cin_perm=None, device="cuda", ck=None) -> PackedConv:
+    """weight (cout, cin, kh, kw) fp32 (any device).  `taps`: list of (dy,dx) to keep (masked
+    convs); `shuffle`: rows permuted for the PixelShuffle(2) store; `cin_perm`: index list applied
+    to input channels (free re-ordering of concatenated inputs)."""
+    w = weight.detach().float().cpu()
+    cout, cin_real, kh, kw = w.shape
+    if cin_perm is not None:
+        w = w[:, cin_perm]
+    b = torch.zeros(cout) if bias is None else bias.detach().float().cpu()
+    if shuffle:
+        assert cout % 4 == 0
+        cq = cout // 4
+        # packed row (i*2+j)*cq + c  <-  original row c*4 + i*2 + j
+        perm = torch.arange(cout).view(cq, 4).t().reshape(-1)
+        w, b = w[perm], b[perm]
+    cin = pad8(cin_real) if cin_pad is None else cin_pad
+    if taps is None:
+        taps = [(dy, dx) for dy in range(kh) for dx in range(kw)]
+    lib = L.lib()
+    if ck is None:
+        ck = lib.tdvc_conv_plan(cin, kh, kw, stride)
+        L.check(0 if ck > 0 else ck, "conv_plan")
+    nbytes = lib.tdvc_conv_packed_bytes(cout, cin, len(taps), ck)
+    assert nbytes > 0
+    dst = np.zeros(nbytes // 2, dtype=np.uint16)
+    wn = np.ascontiguousarray(w.numpy())
+    dy = np.array([t[0] for t in taps], dtype=np.int8)
+    dx = np.array([t[1] for t in taps], dtype=np.int8)
+    L.check(lib.tdvc_pack_conv_weights(wn.ctypes.data, cout, cin_real, cin, kh, kw, len(taps),
+                                       dy.ctypes.data, dx.ctypes.data, ck, dst.ctypes.data), "pack_conv_weights")
+    bp = torch.zeros(_cout_pad(cout))
+    bp[:cout] = b
+    return PackedConv(torch.from_numpy(dst.view(np.uint8)).to(device), bp.to(device), cout, cin, kh, kw, stride, pad,
+                      ck, taps, shuffle)
+
+
+def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, res: FM | None = None,
+         res2: FM | None = None, gdn=GDN_NONE, aux: FM | None = None, square=False, out_dtype=torch.float16,
+         round16=False, nchw_out: torch.Tensor | None = None) -> FM | torch.Tensor:
+    assert x.C == pc.cin, f"conv: input has {x.C} channels, layer packed for {pc.cin}"
+    Ho = (x.H + 2 * pc.pad - pc.kh) // pc.stride + 1
+    Wo = (x.W + 2 * pc.pad - pc.kw) // pc.stride + 1
+    d = L.ConvDesc()
+    d.x = x.desc()
+    d.w = pc.w.data_ptr()
+    d.bias = pc.bias.data_ptr()
+    d.cout, d.ntaps = pc.cout, len(pc.taps)
+    for i, (dy, dx) in enumerate(pc.taps):
+        d.tap_dy[i], d.tap_dx[i] = dy, dx
+    d.kh, d.kw, d.stride, d.pad, d.ck = pc.kh, pc.kw, pc.stride, pc.pad, pc.ck
+    d.square_input, d.gdn = int(square), gdn
+    d.aux = aux.desc() if aux is not None else _NULL_FM
+    d.act, d.slope, d.round_before_act = act, slope, int(round16)
+    d.res = res.desc() if res is not None else _NULL_FM
+    d.res2 = res2.desc() if res2 is not None else _NULL_FM
+    if nchw_out is not None:
+        assert nchw_out.shape == (x.N, pc.cout, Ho, Wo) and nchw_out.dtype == torch.float32 and nchw_out.is_contiguous()
+        d.out_mode = OUT_NCHW_F32
+        d.y = L.FMapDesc(nchw_out.data_ptr(), x.N, Ho, Wo, pc.cout, pc.cout * Ho * Wo, 1, L.F32)
+        ret = nchw_out
+    else:
+        if pc.shuffle:
+            d.out_mode = OUT_SHUFFLE2
+            if out is None:
+                out = FM.empty(x.N, 2 * Ho, 2 * Wo, pad8(pc.cout // 4), dtype=out_dtype, device=x.t.device)
+        else:
+            d.out_mode = OUT_NHWC
+            if out is None:
+                out = FM.empty(x.N, Ho, Wo, pc.cout if out_dtype == torch.float32 else pad8(pc.cout),
+                               dtype=out_dtype, device=x.t.device)
+        d.y = out.desc()
+        ret = out
+    L.check(L.lib().tdvc_conv2d(C.byref(d), _stream()), "conv2d")
+    return ret
+
+
+def dcn_fused(x: FM, om: FM, pc: PackedConv, out: FM, groups=8, act=ACT_NONE, slope=0.0, round16=True) -> FM:
+    d = L.DcnDesc()
+    d.x, d.om, d.y = x.desc(), om.desc(), out.desc()
+    d.w, d.bias = pc.w.data_ptr(), pc.bias.data_ptr()
+    d.groups, d.act, d.slope, d.round_before_act = groups, act, slope, int(round16)
+    L.check(L.lib().tdvc_dcn_fused(C.byref(d), _stream()), "dcn_fused")
+    return out
+
+
+# ----------------------------------------------------------------------------- elementwise / SE
+def scale_act_res(a: FM, out: FM, gate: torch.Tensor | None = None, act=ACT_NONE, slope=0.0, res: FM | None = None,
+                  res_sign=1.0, out2: FM | None = None) -> FM:
+    da, dy = a.desc(), out.desc()
+    dr = res.desc() if res is not None else None
+    d2 = out2.desc() if out2 is not None else None
+    L.check(L.lib().tdvc_scale_act_res(C.byref(da), gate.data_ptr() if gate is not None else None, act, slope,
+                                       C.byref(dr) if dr is not None else None, res_sign, C.byref(dy),
+                                       C.byref(d2) if d2 is not None else None, _stream()), "scale_act_res")
+    return out
+
+
+def add_flow(off: FM, flow: FM):
+    do, df = off.desc(), flow.desc()
+    L.check(L.lib().tdvc_add_flow(C.byref(do), C.byref(df), _stream()), "add_flow")
+
+
+def bcast_add_act(x: FM, b: FM, T: int, slope: float):
+    dx, db = x.desc(), b.desc()
+    L.check(L.lib().tdvc_bcast_add_act(C.byref(dx), C.byref(db), T, slope, _stream()), "bcast_add_act")
+
+
+@dataclass
+class SEParams:
+    w1: torch.Tensor
+    b1: torch.Tensor
+    w2: torch.Tensor
+    b2: torch.Tensor
+    C: int
+    Cmid: int
+
+
+def se_gate(x: FM, p: SEParams) -> torch.Tensor:
+    """gate[N][C] fp32 (`main/model/inflate.py:204-208` without the final multiply)."""
+    npix = x.H * x.W
+    nblocks = max(1, min(512, npix // 256))
+    partial = torch.empty((x.N, nblocks, x.C), dtype=torch.float32, device=x.t.device)
+    gate = torch.empty((x.N, x.C), dtype=torch.float32, device=x.t.device)
+    dx = x.desc()
+    lib = L.lib()
+    L.check(lib.tdvc_channel_sum(C.byref(dx), partial.data_ptr(), nblocks, _stream()), "channel_sum")
+    L.check(lib.tdvc_se_gate(partial.data_ptr(), nblocks, 1.0 / npix, x.N, p.C, p.Cmid, p.w1.data_ptr(),
+                             p.b1.data_ptr(), p.w2.data_ptr(), p.b2.data_ptr(), gate.data_ptr(), _stream()), "se_gate")
+    return gate
+
+
+# ----------------------------------------------------------------------------- resampling
+def upsample2x(x: FM, out: FM | None = None) -> FM:
+    if out is None:
+        out = FM.empty(x.N, 2 * x.H, 2 * x.W, x.C, device=x.t.device)
+    dx, dy = x.desc(), out.desc()
+    L.check(L.lib().tdvc_upsample2x(C.byref(dx), C.byref(dy), _stream()), "upsample2x")
+    return out
+
+
+def avgpool2(x: FM) -> FM:
+    out = FM.empty(x.N, x.H // 2, x.W // 2, x.C, dtype=torch.float32, device=x.t.device)
+    dx, dy = x.desc(), out.desc()
+    L.check(L.lib().tdvc_avgpool2(C.byref(dx), C.byref(dy), _stream()), "avgpool2")
+    return out
+
+
+def spynet_level_input(ref: FM, supp: FM, flow_lo: FM | None, flow_up: FM, cat8: FM):
+    dr, ds, du, dc = ref.desc(), supp.desc(), flow_up.desc(), cat8.desc()
+    dl = flow_lo.desc() if flow_lo is not None else None
+    L.check(L.lib().tdvc_spynet_level_input(C.byref(dr), C.byref(ds), C.byref(dl) if dl is not None else None,
+                                            C.byref(du), C.byref(dc), _stream()), "spynet_level_input")
+
+
+def resize_bilinear(x: FM, H: int, W: int, chscale: torch.Tensor | None = None) -> FM:
+    out = FM.empty(x.N, H, W, x.C, dtype=torch.float32, device=x.t.device)
+    dx, dy = x.desc(), out.desc()
+    L.check(L.lib().tdvc_resize_bilinear(C.byref(dx), C.byref(dy), chscale.data_ptr() if chscale is not None else None,
+                                         _stream()), "resize_bilinear")
+    return out
+
+
+# ----------------------------------------------------------------------------- in-loop filter matching
+def avgpool_k(x: FM, scale: int) -> torch.Tensor:
+    hp, wp = x.H // scale, x.W // scale
+    pooled = torch.empty((x.N, hp, wp, x.C), dtype=torch.float32, device=x.t.device)
+    dx = x.desc()
+    L.check(L.lib().tdvc_avgpool_k(C.byref(dx), scale, pooled.data_ptr(), hp, wp, _stream()), "avgpool_k")
+    return pooled
+
+
+def patch_match(pin: torch.Tensor, pref: torch.Tensor) -> torch.Tensor:
+    N, hp, wp, Cc = pin.shape
+    Lp = ((hp + 3) // 3 + 1) * ((wp + 3) // 3 + 1)
+    idx = torch.empty((N, Lp), dtype=torch.int32, device=pin.device)
+    L.check(L.lib().tdvc_patch_match(pin.data_ptr(), pref.data_ptr(), N, hp, wp, Cc, idx.data_ptr(), _stream()),
+            "patch_match")
+    return idx
+
+
+def match_gather(fin: FM, fref: FM, idx: torch.Tensor, scale: int, cat: FM):
+    df, dr, dc = fin.desc(), fref.desc(), cat.desc()
+    L.check(L.lib().tdvc_match_gather(C.byref(df), C.byref(dr), idx.data_ptr(), scale, fin.H // scale, fin.W // scale,
+                                      C.byref(dc), _stream()), "match_gather")
+
+
+# ----------------------------------------------------------------------------- entropy model
+def eb_forward(z: FM, params: torch.Tensor, z_hat: FM, bits_out: torch.Tensor, noise: FM | None = None):
+    numel = z.N * z.H * z.W * z.C
+    cap = (numel + 255) // 256
+    partial = torch.empty(cap, dtype=torch.float32, device=z.t.device)
+    dz, dh = z.desc(), z_hat.desc()
+    dn = noise.desc() if noise is not None else None
+    L.check(L.lib().tdvc_eb_forward(C.byref(dz), params.data_ptr(), C.byref(dn) if dn is not None else None, C.byref(dh),
+                                    bits_out.data_ptr(), partial.data_ptr(), cap, _stream()), "eb_forward")
+
+
+def gc_forward(y: FM, gp: FM, bits_out: torch.Tensor, noise: FM | None = None):
+    numel = y.N * y.H * y.W * y.C
+    cap = (numel + 255) // 256
+    partial = torch.empty(cap, dtype=torch.float32, device=y.t.device)
+    dy, dg = y.desc(), gp.desc()
+    dn = noise.desc() if noise is not None else None
+    L.check(L.lib().tdvc_gc_forward(C.byref(dy), C.byref(dg), C.byref(dn) if dn is not None else None,
+                                    bits_out.data_ptr(), partial.data_ptr(), cap, _stream()), "gc_forward")
+
+
+def quantize(y: FM, out: FM, noise: FM | None = None) -> FM:
+    dy, do = y.desc(), out.desc()
+    dn = noise.desc() if noise is not None else None
+    L.check(L.lib().tdvc_quantize(C.byref(dy), C.byref(dn) if dn is not None else None, C.byref(do), _stream()), "quantize")
+    return out
+
+
+# ----------------------------------------------------------------------------- `_ext` operator
+def dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, deformable_group):
+    """Same arity / semantics as `_ext.dcn_v2_forward` (src/vision.cpp:3-8): fp32 contiguous
+    NCHW cuda tensors in, freshly allocated output out; raises RuntimeError on violations
+    (the reference raises through AT_ASSERTM, src/cuda/dcn_v2_cuda.cu:38-62)."""
+    ts = (input, weight, bias, offset, mask)
+    for t in ts:
+        if not (torch.is_tensor(t) and t.is_cuda):
+            raise RuntimeError("dcn_v2_forward: all tensors must be CUDA/HIP tensors (Not compiled with CPU support)")
+        if t.dtype != torch.float32:
+            raise RuntimeError("dcn_v2_forward: fp32 tensors only")
+    input, weight, bias, offset, mask = [t.contiguous() for t in ts]
+    B, Cc, H, W = input.shape
+    Cout, Ck, kh_, kw_ = weight.shape
+    if (kh_, kw_) != (kh, kw):
+        raise RuntimeError(f"Input shape and kernel shape wont match: ({kh} x {kw} vs {kh_} x {kw_}).")
+    if Cc != Ck:
+        raise RuntimeError(f"Input shape and kernel channels wont match: ({Cc} vs {Ck}).")
+    Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    if offset.shape != (B, 2 * deformable_group * kh * kw, Ho, Wo) or mask.shape != (B, deformable_group * kh * kw, Ho, Wo):
+        raise RuntimeError("dcn_v2_forward: offset/mask shape mismatch")
+    out = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=input.device)
+    with torch.cuda.device(input.device):
+        L.check(L.lib().tdvc_dcn_v2_forward_f32(input.data_ptr(), weight.data_ptr(), bias.data_ptr(), offset.data_ptr(),
+                                                mask.data_ptr(), out.data_ptr(), B, Cc, H, W, Cout, kh, kw, sh, sw, ph, pw,
+                                                dh, dw, deformable_group, _stream()), "dcn_v2_forward")
+    return out

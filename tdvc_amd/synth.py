@@ -141,3 +141,12 @@ def ref_list(refs: list) -> torch.Tensor:
     else:
         sel = [refs[0], refs[-3], refs[-2], refs[-1]]
     return torch.stack(sel, dim=1)
+
+
+def split_optim_params(net):
+    """`configure_optimizers` partition of `main/utils/utils.py:90-113`: (main, aux) parameter
+    names; aux = names ending `.quantiles` (Adam lr vs Adam 10*lr)."""
+    main = sorted(n for n, p in net.named_parameters() if not n.endswith(".quantiles") and p.requires_grad)
+    aux = sorted(n for n, p in net.named_parameters() if n.endswith(".quantiles") and p.requires_grad)
+    assert not (set(main) & set(aux))
+    return main, aux

@@ -1,0 +1,171 @@
+"""MFMA conv kernel vs torch fp32 conv on fp16-rounded operands (so the only differences are
+fp32 summation order and the final fp16 rounding of the output)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import assert_close, fm_to_cpu, randn, rnd16, to_fm
+
+pytestmark = pytest.mark.gpu
+
+RT, AT = 2e-3, 2e-3
+
+
+def _ops():
+    from tdvc_amd import ops
+    return ops
+
+
+CASES = [
+    # name, N, cin, cout, k, stride, pad, H, W
+    ("3x3_64_64", 1, 64, 64, 3, 1, 1, 24, 40),
+    ("3x3_64_64_big", 2, 64, 64, 3, 1, 1, 70, 100),
+    ("3x3_s2_64_128", 1, 64, 128, 3, 2, 1, 32, 48),
+    ("3x3_s2_odd", 1, 128, 128, 3, 2, 1, 18, 30),
+    ("1x1_128_64", 1, 128, 64, 1, 1, 0, 20, 36),
+    ("1x1_s2_64_128", 1, 64, 128, 1, 2, 0, 32, 64),
+    ("1x1_256_64", 1, 256, 64, 1, 1, 0, 16, 40),
+    ("3x3_3_64", 1, 3, 64, 3, 1, 1, 33, 47),
+    ("7x7_8_32", 1, 8, 32, 7, 1, 3, 34, 60),
+    ("7x7_32_64", 1, 32, 64, 7, 1, 3, 17, 30),
+    ("7x7_64_32", 1, 64, 32, 7, 1, 3, 17, 30),
+    ("7x7_32_16", 1, 32, 16, 7, 1, 3, 9, 15),
+    ("3x3_128_192", 1, 128, 192, 3, 1, 1, 17, 30),
+    ("1x1_512_426", 1, 512, 426, 1, 1, 0, 8, 15),
+    ("1x1_426_341", 1, 426, 341, 1, 1, 0, 8, 15),
+    ("3x3_64_216", 1, 64, 216, 3, 1, 1, 16, 32),
+    ("3x3_192_256", 1, 192, 256, 3, 1, 1, 8, 12),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_plain(case, report):
+    ops = _ops()
+    name, N, cin, cout, k, s, p, H, W = case
+    x = rnd16(randn(N, cin, H, W, seed=1))
+    w = rnd16(randn(cout, cin, k, k, seed=2) * (1.0 / (cin * k * k) ** 0.5))
+    b = randn(cout, seed=3) * 0.1
+    ref = F.leaky_relu(F.conv2d(x, w, b, stride=s, padding=p), 0.1)
+    pc = ops.pack_conv(w, b, stride=s, pad=p)
+    y = ops.conv(to_fm(x, ops), pc, act=ops.ACT_LRELU, slope=0.1)
+    got = fm_to_cpu(y, cout)
+    assert_close(got, ref, RT, AT, f"conv {name}", report)
+    if y.C > cout:      # padded channels must be exactly zero (they feed the next layer)
+        assert float(fm_to_cpu(y)[:, cout:].abs().max()) == 0.0
+
+
+def test_conv_residuals_and_slices(report):
+    ops = _ops()
+    x = rnd16(randn(2, 128, 20, 36, seed=4))
+    w = rnd16(randn(64, 64, 3, 3, seed=5) * 0.05)
+    b = randn(64, seed=6) * 0.1
+    r1 = rnd16(randn(2, 64, 20, 36, seed=7))
+    r2 = rnd16(randn(2, 64, 20, 36, seed=8))
+    ref = F.relu(F.conv2d(x[:, 64:], w, b, padding=1)) + r1 + r2
+    xf = to_fm(x, ops)
+    out = ops.FM.zeros(2, 20, 36, 192)
+    ops.conv(xf.ch(64, 64), ops.pack_conv(w, b, stride=1, pad=1), out=out.ch(128, 64), act=ops.ACT_RELU,
+             res=to_fm(r1, ops), res2=to_fm(r2, ops))
+    full = fm_to_cpu(out)
+    assert_close(full[:, 128:], ref, RT, AT, "conv slice-in/slice-out + 2 residuals", report)
+    assert float(full[:, :128].abs().max()) == 0.0
+
+
+def test_conv_cin_perm(report):
+    ops = _ops()
+    x = rnd16(randn(1, 128, 16, 32, seed=9))
+    w = rnd16(randn(64, 128, 3, 3, seed=10) * 0.03)
+    ref = F.conv2d(torch.cat([x[:, 64:], x[:, :64]], 1), w, None, padding=1)
+    perm = list(range(64, 128)) + list(range(0, 64))
+    y = ops.conv(to_fm(x, ops), ops.pack_conv(w, None, stride=1, pad=1, cin_perm=perm))
+    assert_close(fm_to_cpu(y), ref, RT, AT, "conv cin_perm", report)
+
+
+def test_conv_frames_as_slices(report):
+    """Conv3d(1,3,3) over a (B,H,W,T*64) buffer == per-frame 2-D conv"""
+    ops = _ops()
+    B, T, H, W = 2, 4, 16, 32
+    x = rnd16(randn(B, T * 64, H, W, seed=11))
+    w = rnd16(randn(64, 64, 3, 3, seed=12) * 0.05)
+    b = randn(64, seed=13) * 0.1
+    src, dst = to_fm(x, ops), ops.FM.zeros(B, H, W, T * 64)
+    pc = ops.pack_conv(w, b, stride=1, pad=1)
+    for bi in range(B):
+        ops.conv(src.as_slices(bi, T, 64), pc, out=dst.as_slices(bi, T, 64))
+    got = fm_to_cpu(dst)
+    ref = torch.cat([F.conv2d(x[:, t * 64:(t + 1) * 64], w, b, padding=1) for t in range(T)], 1)
+    assert_close(got, ref, RT, AT, "conv over frame slices", report)
+
+
+def test_conv_masked5x5(report):
+    ops = _ops()
+    x = rnd16(randn(1, 128, 17, 30, seed=14))
+    w = rnd16(randn(256, 128, 5, 5, seed=15) * 0.02)
+    b = randn(256, seed=16) * 0.1
+    mask = torch.ones_like(w)
+    mask[:, :, 2, 2:] = 0
+    mask[:, :, 3:] = 0
+    ref = F.conv2d(x, w * mask, b, padding=2)
+    taps = [(dy, dx) for dy in range(5) for dx in range(5) if dy < 2 or (dy == 2 and dx < 2)]
+    y = ops.conv(to_fm(x, ops), ops.pack_conv(w, b, stride=1, pad=2, taps=taps))
+    assert_close(fm_to_cpu(y), ref, RT, AT, "masked 5x5 context conv", report)
+
+
+@pytest.mark.parametrize("cin,cout", [(128, 128), (192, 192), (128, 64)])
+def test_conv_pixel_shuffle(cin, cout, report):
+    ops = _ops()
+    x = rnd16(randn(1, cin, 9, 15, seed=17))
+    w = rnd16(randn(cout * 4, cin, 3, 3, seed=18) * 0.03)
+    b = randn(cout * 4, seed=19) * 0.1
+    r = rnd16(randn(1, cout, 18, 30, seed=20))
+    ref = F.leaky_relu(F.pixel_shuffle(F.conv2d(x, w, b, padding=1), 2), 0.01) + r
+    y = ops.conv(to_fm(x, ops), ops.pack_conv(w, b, stride=1, pad=1, shuffle=True), act=ops.ACT_LRELU, slope=0.01,
+                 res=to_fm(r, ops))
+    assert_close(fm_to_cpu(y), ref, RT, AT, f"subpel conv {cin}->{cout}", report)
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_conv_gdn(inverse, report):
+    ops = _ops()
+    C = 128
+    x = rnd16(randn(1, C, 12, 20, seed=21))
+    gamma = rnd16(torch.rand(C, C, generator=torch.Generator().manual_seed(22)) * 0.02 + 0.1 * torch.eye(C))
+    beta = torch.rand(C, generator=torch.Generator().manual_seed(23)) + 0.5
+    r = rnd16(randn(1, C, 12, 20, seed=24))
+    norm = F.conv2d(rnd16(x * x), gamma.view(C, C, 1, 1), beta)
+    ref = x * (torch.sqrt(norm) if inverse else torch.rsqrt(norm)) + r
+    xf = to_fm(x, ops)
+    y = ops.conv(xf, ops.pack_conv(gamma.view(C, C, 1, 1), beta, stride=1, pad=0), square=True,
+                 gdn=ops.GDN_INV if inverse else ops.GDN_FWD, aux=xf, res=to_fm(r, ops))
+    assert_close(fm_to_cpu(y), ref, 3e-3, 3e-3, f"GDN inverse={inverse}", report)
+
+
+def test_conv_f32_out_flow_residual_and_nchw(report):
+    ops = _ops()
+    x = rnd16(randn(1, 16, 17, 30, seed=25))
+    w = rnd16(randn(2, 16, 7, 7, seed=26) * 0.05)
+    b = randn(2, seed=27) * 0.1
+    up = randn(1, 2, 17, 30, seed=28)
+    ref = F.conv2d(x, w, b, padding=3) + up
+    y = ops.conv(to_fm(x, ops), ops.pack_conv(w, b, stride=1, pad=3), res=to_fm(up, ops, Cpad=2, dtype=torch.float32),
+                 out_dtype=torch.float32)
+    assert y.f32 and y.C == 2
+    assert_close(fm_to_cpu(y), ref, 1e-4, 1e-4, "7x7 16->2 fp32 out + fp32 residual", report)
+    # featdown: 64 -> 3, clamp, planar fp32
+    x = rnd16(randn(2, 64, 20, 36, seed=29))
+    w = rnd16(randn(3, 64, 3, 3, seed=30) * 0.1)
+    b = torch.tensor([0.5, 0.4, 0.6])
+    ref = F.conv2d(x, w, b, padding=1).clamp(0, 1)
+    out = torch.empty(2, 3, 20, 36, device="cuda")
+    ops.conv(to_fm(x, ops), ops.pack_conv(w, b, stride=1, pad=1), act=ops.ACT_CLAMP01, nchw_out=out)
+    assert_close(out.cpu(), ref, 1e-4, 1e-4, "featdown NCHW fp32 + clamp", report)
+
+
+def test_conv_errors():
+    ops = _ops()
+    from tdvc_amd._lib import TdvcHipError
+    x = to_fm(randn(1, 64, 16, 16), ops)
+    pc = ops.pack_conv(randn(64, 64, 3, 3), None, stride=1, pad=1)
+    bad = ops.FM.empty(1, 8, 8, 64)
+    with pytest.raises(TdvcHipError):
+        ops.conv(x, pc, out=bad)

@@ -1,0 +1,96 @@
+"""Deformable conv: fused fp16 kernel and the fp32 `_ext` operator vs the oracle; the
+reference's own known-answer test `check_zero_offset` (main/utils/dcnv2/testcpu.py:34-69)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import assert_close, fm_to_cpu, randn, rnd16, to_fm
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ext_zero_offset_kat(report):
+    """zero offsets, mask = sigmoid(0) = 0.5, identity centre-tap weights => 2*output == input"""
+    import _ext
+    N, inC, inH, inW, outC, k = 2, 2, 4, 4, 2, 3
+    w = torch.zeros(outC, inC, k, k)
+    for c in range(inC):
+        w[c, c, 1, 1] = 1.0
+    x = randn(N, inC, inH, inW, seed=1)
+    offset = torch.zeros(N, 2 * k * k, inH, inW)
+    mask = torch.sigmoid(torch.zeros(N, k * k, inH, inW))
+    out = _ext.dcn_v2_forward(x.cuda(), w.cuda(), torch.zeros(outC).cuda(), offset.cuda(), mask.cuda(),
+                              k, k, 1, 1, 1, 1, 1, 1, 1)
+    d = float((x - 2 * out.cpu()).abs().max())
+    report(f"check_zero_offset: max|input - 2*output| = {d:.3e}")
+    assert d < 1e-10
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, C=2, Cout=2, H=4, W=4, k=3, s=1, p=1, d=1, G=1, osc=2.0),      # testcpu.py geometry
+    dict(B=1, C=64, Cout=64, H=20, W=28, k=3, s=1, p=1, d=1, G=8, osc=3.0),  # hot-path geometry
+    dict(B=2, C=16, Cout=24, H=11, W=13, k=3, s=2, p=1, d=1, G=4, osc=1.5),
+    dict(B=1, C=8, Cout=8, H=9, W=9, k=3, s=1, p=2, d=2, G=2, osc=4.0),
+])
+def test_ext_forward_vs_oracle(cfg, report):
+    import _ext
+    from oracle.tdvc_ref.blocks import dcn_v2_forward_ref
+    B, C, Cout, H, W, k, s, p, d, G = (cfg[x] for x in ("B", "C", "Cout", "H", "W", "k", "s", "p", "d", "G"))
+    Ho = (H + 2 * p - (d * (k - 1) + 1)) // s + 1
+    Wo = (W + 2 * p - (d * (k - 1) + 1)) // s + 1
+    x = randn(B, C, H, W, seed=2)
+    w = randn(Cout, C, k, k, seed=3, scale=0.2)
+    b = randn(Cout, seed=4)
+    off = randn(B, 2 * G * k * k, Ho, Wo, seed=5, scale=cfg["osc"])
+    m = torch.sigmoid(randn(B, G * k * k, Ho, Wo, seed=6))
+    ref = dcn_v2_forward_ref(x, w, b, off, m, k, k, s, s, p, p, d, d, G)
+    got = _ext.dcn_v2_forward(x.cuda(), w.cuda(), b.cuda(), off.cuda(), m.cuda(), k, k, s, s, p, p, d, d, G).cpu()
+    assert_close(got, ref, 1e-5, 1e-5, f"_ext.dcn_v2_forward {cfg}", report)
+
+
+def test_ext_errors():
+    import _ext
+    x = torch.zeros(1, 4, 8, 8).cuda()
+    w = torch.zeros(4, 4, 3, 3).cuda()
+    b = torch.zeros(4).cuda()
+    off = torch.zeros(1, 18, 8, 8).cuda()
+    m = torch.zeros(1, 9, 8, 8).cuda()
+    with pytest.raises(RuntimeError):
+        _ext.dcn_v2_forward(x, w, b, off, m, 5, 5, 1, 1, 1, 1, 1, 1, 1)          # kernel shape mismatch
+    with pytest.raises(RuntimeError):
+        _ext.dcn_v2_forward(x.cpu(), w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)    # CPU tensor
+    with pytest.raises(RuntimeError):
+        _ext.dcn_v2_forward(x, torch.zeros(4, 3, 3, 3).cuda(), b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+
+
+@pytest.mark.parametrize("H,W", [(20, 28), (64, 96)])
+def test_fused_dcn_vs_oracle(H, W, report):
+    """fp16 fused kernel (sampling + modulation + contraction + fp16 rounding + LeakyReLU) vs the
+    oracle DCN module fed the same fp16-rounded operands"""
+    from tdvc_amd import ops
+    from oracle.tdvc_ref.blocks import DCN as RefDCN
+    from tdvc_amd.model.modules import DCN
+    from tdvc_amd.synth import fill_parameters
+    ref = RefDCN(64, 64, 3, 1, 1, deformable_groups=8).eval()
+    hold = torch.nn.Module(); hold.add_module("dconv", ref); fill_parameters(hold)
+    with torch.no_grad():
+        for p_ in ref.parameters():
+            p_.copy_(rnd16(p_))
+        ref.conv_offset_mask.weight.mul_(3.0)      # offsets of a few pixels
+    m = DCN(64, 64, 3, 1, 1, deformable_groups=8)
+    m.load_state_dict(ref.state_dict())
+    m.cuda()
+    x = rnd16(randn(2, 64, H, W, seed=7))
+    y = rnd16(randn(2, 64, H, W, seed=8))
+    with torch.no_grad():
+        # the oracle's offsets come from an fp32 conv; round them like the fp16 path does
+        offset, mask_ = ref.offsets_and_mask(y)
+        om = ref.conv_offset_mask(y)
+        om16 = rnd16(om)
+        o1, o2, ml = torch.chunk(om16, 3, 1)
+        from oracle.tdvc_ref.blocks import dcn_v2_forward_ref
+        out = dcn_v2_forward_ref(x, ref.weight, ref.bias, torch.cat((o1, o2), 1), torch.sigmoid(ml), 3, 3, 1, 1, 1, 1, 1, 1, 8)
+        want = F.leaky_relu(out.half(), 0.1).float()
+    dst = ops.FM.empty(2, H, W, 64)
+    m.run(to_fm(x, ops), to_fm(y, ops), dst, act=ops.ACT_LRELU, slope=0.1)
+    assert_close(fm_to_cpu(dst), want, 4e-3, 4e-3, f"fused DCN {H}x{W}", report)

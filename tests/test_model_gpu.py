@@ -1,0 +1,90 @@
+"""End-to-end: MI355X `VideoCompressor` vs the CPU oracle on identical weights and inputs.
+
+Gates: |dPSNR| <= 0.02 dB and |dbpp| <= 0.001 against the oracle; stage-wise
+drift is reported (fp16 activations vs the fp32 oracle) and bounded loosely per stage."""
+import math
+
+import pytest
+import torch
+
+from util import fm_to_cpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _build():
+    from oracle.tdvc_ref import VideoCompressor as Ref
+    from tdvc_amd.model import VideoCompressor
+    from tdvc_amd.synth import fill_parameters
+    ref = Ref().eval()
+    fill_parameters(ref)
+    m = VideoCompressor()
+    m.load_state_dict(ref.state_dict(), strict=True)
+    return ref, m.cuda().eval()
+
+
+def psnr(a, b):
+    return 10 * math.log10(1.0 / float(((a - b) ** 2).mean()))
+
+
+@pytest.fixture(scope="module")
+def models():
+    return _build()
+
+
+def rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (128, 192)])
+def test_forward_vs_oracle(models, H, W, report):
+    from tdvc_amd.synth import make_gop, ref_list
+    ref, m = models
+    g = make_gop(1234, 4, H, W)
+    refs_o, refs_g = [g[0:1]], [g[0:1].cuda()]
+    for t in range(1, 4):
+        tr_o, tr_g = {}, {}
+        with torch.no_grad():
+            ro, bro, bmo = ref(g[t:t + 1], ref_list(refs_o), False, trace=tr_o)
+            rg, brg, bmg = m(g[t:t + 1].cuda(), ref_list(refs_g), True, trace=tr_g)
+        rg_c = rg.cpu()
+        stages = {}
+        for k in ("f_cur", "f_ref", "estmv", "mv_x_hat", "pred1", "pred", "resid", "recon_f"):
+            stages[k] = rel(fm_to_cpu(tr_g[k]), tr_o[k].float())
+        for c in ("mv", "res"):
+            dbg = tr_o[c + "_dbg"]
+            stages[c + ".y"] = rel(fm_to_cpu(tr_g[c]["y"]), dbg["y"])
+            stages[c + ".z"] = rel(fm_to_cpu(tr_g[c]["z"]), dbg["z"])
+            yh_g, yh_o = fm_to_cpu(tr_g[c]["y_hat"]), dbg["y_hat"]
+            stages[c + ".y_hat_flips"] = float((yh_g != yh_o).float().mean())
+            gp = fm_to_cpu(tr_g[c]["gp"])
+            stages[c + ".scales"] = rel(gp[:, :128], dbg["scales"])
+            stages[c + ".means"] = rel(gp[:, 128:], dbg["means"])
+        p_o, p_g = psnr(ro, g[t:t + 1]), psnr(rg_c, g[t:t + 1])
+        report(f"[{H}x{W} frame {t}] PSNR oracle {p_o:.4f} gpu {p_g:.4f} | bpp_res {float(bro):.5f}/{float(brg):.5f} "
+               f"bpp_mv {float(bmo):.5f}/{float(bmg):.5f} | recon maxabs diff {float((ro - rg_c).abs().max()):.4f} "
+               f"PSNR(gpu,oracle) {psnr(rg_c, ro):.2f} dB")
+        report("   stage rel-L2: " + " ".join(f"{k}={v:.2e}" for k, v in stages.items()))
+        assert abs(p_o - p_g) <= 0.02, f"PSNR delta {p_o - p_g}"
+        assert abs(float(bro) - float(brg)) <= 1e-3 * max(1.0, float(bro)), "bpp_res delta"
+        assert abs(float(bmo) - float(bmg)) <= 1e-3 * max(1.0, float(bmo)), "bpp_mv delta"
+        for k in ("f_cur", "f_ref", "estmv"):
+            assert stages[k] < 1e-2, (k, stages[k])
+        # both decoders continue from their own reconstruction (closed loop), like tools/predict.py:68
+        refs_o.append(ro)
+        refs_g.append(rg)
+
+
+def test_module_api(models):
+    """drop-in surface used by tools/train.py / tools/predict.py"""
+    from tdvc_amd.synth import split_optim_params
+    ref, m = models
+    assert type(m).__name__ == "VideoCompressor"
+    main, aux = split_optim_params(m)
+    assert len(aux) == 2 and all(n.endswith(".quantiles") for n in aux)
+    assert set(m.state_dict().keys()) == set(ref.state_dict().keys())
+    x = torch.zeros(1, 3, 60, 64).cuda()
+    with pytest.raises(RuntimeError):
+        m(x, torch.zeros(1, 4, 3, 60, 64).cuda(), True)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 64, 64), torch.zeros(1, 4, 3, 64, 64), True)
