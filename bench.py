@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""bench.py — 1080p P-frames/s of the MI355X-native TDVC encode/reconstruct path.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched under
+torch.distributed.run (one rank per GPU).  A *step* is one P-frame through
+`VideoCompressor.forward` (eval mode: both coders' analysis + entropy model rate + synthesis,
+motion compensation, fusion, in-loop filter) at 1088x1920 (1080p padded to x64), batch 1, coded
+in GOP order with the reference-list rule of tools/predict.py:55-62 (closed loop on the GPU's own
+reconstructions).  Inputs are resident in HBM before the timed region.  Ranks code independent
+GOPs (GOP sharding, no collective on the data path): weak scaling.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md §measurement for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_PX = 7_664_102            # 2 x 3 832 051 MAC per padded pixel, one P-frame forward
+MFMA_F16_PEAK = 2.5e15             # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
+HP, WP = 1088, 1920
+
+
+def build_model(dev):
+    from tdvc_amd.model import VideoCompressor
+    from tdvc_amd.synth import fill_parameters
+    m = VideoCompressor()
+    fill_parameters(m)
+    return m.to(dev).eval()
+
+
+def make_inputs(seed, dev):
+    from tdvc_amd.synth import make_gop
+    import torch.nn.functional as F
+    g = make_gop(seed, 7, 1080, 1920)
+    g = F.pad(g, (0, 0, 4, 4))                  # utils.pad(.., 64): 1080 -> 1088, centred
+    return g.to(dev)
+
+
+class GopRunner:
+    """codes P-frames 1..6 of a 7-frame GOP in order, then starts over"""
+
+    def __init__(self, model, gop):
+        self.m, self.g, self.t, self.refs = model, gop, 0, None
+
+    def step(self):
+        from tdvc_amd.synth import ref_list
+        if self.t == 0:
+            self.refs = [self.g[0:1]]
+        self.t += 1
+        recon, bpp_res, bpp_mv = self.m(self.g[self.t:self.t + 1], ref_list(self.refs), True)
+        self.refs.append(recon)
+        if self.t == 6:
+            self.t = 0
+        return recon, bpp_res, bpp_mv
+
+
+def cpu_baseline(sample_hw=(512, 960)):
+    """the CPU oracle (fp32 PyTorch restatement) timed on this box's host cores on a bounded sample"""
+    from oracle.tdvc_ref import VideoCompressor as Ref
+    from tdvc_amd.synth import fill_parameters, make_gop, ref_list
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))      # a 1-GPU box's CPU share is 16 cores; more threads only oversubscribe
+    torch.set_num_threads(cores)
+    ref = Ref().eval()
+    fill_parameters(ref)
+    h, w = sample_hw
+    g = make_gop(1234, 2, h, w)
+    refs = ref_list([g[0:1]])
+    with torch.no_grad():
+        t0 = time.time()
+        ref(g[1:2], refs, False)
+        dt = time.time() - t0
+    frac = (h * w) / float(HP * WP)
+    return {"value": round(frac / dt, 5), "unit": "1080p P-frames/s (area-scaled)", "cores": torch.get_num_threads(),
+            "kind": "port", "seconds": round(dt, 2),
+            "sample": f"1 P-frame forward of the fp32 PyTorch oracle at {h}x{w} ({frac:.3f} of the 1088x1920 pixels), fps scaled by area"}
+
+
+def roofline_leg(runner):
+    """one extra P-frame with HIP events around every conv launch (torch's current stream is the
+    launch stream).  Dominant kernel = the MFMA conv instantiation with the largest total time."""
+    from tdvc_amd import ops
+    ops.PROFILE = []
+    runner.step()
+    torch.cuda.synchronize()
+    prof, ops.PROFILE = ops.PROFILE, None
+    agg = {}
+    for r in prof:
+        a = agg.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, n=0))
+        a["ms"] += r["e0"].elapsed_time(r["e1"])
+        a["flops"] += r["flops_real"]
+        a["n"] += 1
+    name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+    tot_ms = sum(v["ms"] for v in agg.values())
+    tot_fl = sum(v["flops"] for v in agg.values())
+    ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s",
+            "frac": round(ach * 1e12 / MFMA_F16_PEAK, 4), "traffic": None, "launches_per_frame": a["n"],
+            "avg_launch_ms": round(a["ms"] / a["n"], 4), "kernel_ms_per_frame": round(a["ms"], 3),
+            "all_conv_ms_per_frame": round(tot_ms, 3), "all_conv_tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+            "by_kernel": {k: {"ms": round(v["ms"], 3), "n": v["n"], "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                          for k, v in sorted(agg.items())}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    model = build_model(dev)
+    gop = make_inputs(2000 + 100 * rank, dev)           # independent GOP per rank (SURVEY §8d seeds)
+    runner = GopRunner(model, gop)
+    for _ in range(a.warmup):
+        runner.step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        recon, bpp_res, bpp_mv = runner.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        dt = float(t)
+    torch.cuda.synchronize()
+
+    if rank == 0:
+        fps = a.gpus * a.steps / dt
+        roof = roofline_leg(runner)
+        line = {
+            "metric": "1080p P-frames/sec (encode + reconstruct, lambda=2048 config)", "value": round(fps, 3),
+            "unit": "frames/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "1x 1920x1080 (padded 1088x1920) 7-frame synthetic GOP, batch 1, P-frames coded in GOP order",
+                       "gop": 7, "batch": 1, "parallelism": f"gop-sharded x{a.gpus}", "weights": "closed-form filler (no checkpoint ships)"},
+            "whole_path_tflops": round(FLOP_PER_PX * HP * WP * fps / a.gpus / 1e12, 2),
+            "whole_path_frac_of_mfma_peak": round(FLOP_PER_PX * HP * WP * fps / a.gpus / MFMA_F16_PEAK, 4),
+            "bpp_last": round(float(bpp_res + bpp_mv), 5),
+            "roofline": roof,
+        }
+        print("[bench] gpu leg: " + json.dumps(line), file=sys.stderr, flush=True)
+        if a.gpus == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -614,7 +614,7 @@ extern "C" int tdvc_bcast_add_act(const tdvc_fmap* x, const tdvc_fmap* b, int T,
 }
 
 extern "C" int tdvc_channel_sum(const tdvc_fmap* x, float* partial, int nblocks, void* stream) {
-  TDVC_CHECK(x && partial && fmap_ok16(*x) && x->C <= 256 && nblocks >= 1 && nblocks <= 4096, "tdvc_channel_sum: bad arguments");
+  TDVC_CHECK(x && partial && fmap_any(*x) && (x->C % 8) == 0 && x->C <= 256 && nblocks >= 1 && nblocks <= 4096, "tdvc_channel_sum: bad arguments");
   hipLaunchKernelGGL(channel_sum_kernel, dim3(nblocks, x->N), dim3(256), 0, ST(stream), to_dev(*x), partial, nblocks);
   return tdvc_launch_status("tdvc_channel_sum");
 }

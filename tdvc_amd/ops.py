@@ -21,6 +21,10 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# optional per-launch event trace (bench.py roofline leg): list of dicts, or None
+PROFILE = None
+
+
 def pad8(c: int) -> int:
     return (c + 7) // 8 * 8
 
@@ -107,6 +111,7 @@ class PackedConv:
     ck: int
     taps: list               # [(dy, dx)]
     shuffle: bool = False
+    cin_real: int = 0        # un-padded input channels (algorithmic FLOP accounting)
 
 
 def _cout_pad(cout):
@@ -147,7 +152,7 @@ def pack_conv(weight: torch.Tensor, bias: torch.Tensor | None, stride=1, pad=0, 
     bp = torch.zeros(_cout_pad(cout))
     bp[:cout] = b
     return PackedConv(torch.from_numpy(dst.view(np.uint8)).to(device), bp.to(device), cout, cin, kh, kw, stride, pad,
-                      ck, taps, shuffle)
+                      ck, taps, shuffle, cin_real)
 
 
 def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, res: FM | None = None,
@@ -186,6 +191,16 @@ def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, 
                                dtype=out_dtype, device=x.t.device)
         d.y = out.desc()
         ret = out
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(L.lib().tdvc_conv2d(C.byref(d), _stream()), "conv2d")
+        e1.record()
+        PROFILE.append(dict(kernel=f"conv_mfma<{pc.ck // 8},{1 if pc.cout <= 32 else 2},{pc.stride}>", e0=e0, e1=e1,
+                            flops=2.0 * x.N * Ho * Wo * pc.cout * x.C * len(pc.taps),
+                            flops_real=2.0 * x.N * Ho * Wo * pc.cout * pc.cin_real * len(pc.taps),
+                            bytes=2.0 * x.N * (x.H * x.W * x.C + Ho * Wo * pc.cout * (4 if pc.shuffle else 1) / (4 if pc.shuffle else 1))))
+        return ret
     L.check(L.lib().tdvc_conv2d(C.byref(d), _stream()), "conv2d")
     return ret
 

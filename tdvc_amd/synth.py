@@ -67,7 +67,9 @@ def fill_parameters(module: torch.nn.Module) -> None:
       * last SPyNet conv of each level (16->2): scaled by 0.05 so the synthetic flow
         stays within a few pixels
       * last conv of each analysis transform (`g_a.7`): x4 so latents span several bins;
-        `loopfilter.featdown`: weight x0.25, bias +0.5 so the output is not clamped away
+        `loopfilter.featdown`: weight x0.25, bias +0.5 so the output is not clamped away;
+        `entropy_parameters.4.bias[:N]` (+1.5): predicted Gaussian scales of order 1, so the
+        synthetic rate is a few bits per latent instead of sitting on the 1e-9 likelihood floor
     """
     with torch.no_grad():
         for name, p in module.named_parameters():
@@ -95,6 +97,8 @@ def fill_parameters(module: torch.nn.Module) -> None:
                 p.copy_(_uniform_like(p, name, 0.05))
                 if name.endswith("loopfilter.featdown.bias"):
                     p.add_(0.5)         # keep the synthetic reconstruction inside (0, 1)
+                if name.endswith("entropy_parameters.4.bias"):
+                    p[: p.numel() // 2].add_(1.5)   # predicted scales ~1.5: a sane (not 1e-9-floor) rate model
 
 
 def _box_blur(a: np.ndarray, k: int) -> np.ndarray:
