@@ -2,10 +2,9 @@
 // (SURVEY §8 a11/a12).
 //
 // (1) tdvc_dcn_fused: fp16 NHWC, sampling + modulation + 64x576 contraction in ONE kernel.
-//     The reference materialises `columns` (576 values / pixel = 4.8 GB at 1080p,
-//     src/cuda/dcn_v2_cuda.cu:67-92); here each lane bilinearly samples the 8 channels of one
-//     deformable group (= one 16-byte NHWC chunk per corner) straight into the MFMA B fragment
-//     (B[k = 8*(lane>>5)+j][pixel = lane&31]), so sampled values never leave registers.
+//     The reference materialises `columns` in HBM (576 values / pixel = 4.8 GB at 1080p,
+//     src/cuda/dcn_v2_cuda.cu:67-92); here the modulated samples of an 8x8 pixel tile live in a
+//     25 KB LDS tile, three taps at a time, and are consumed as MFMA B fragments.
 // (2) tdvc_dcn_v2_forward_f32: fp32 NCHW operator with `_ext.dcn_v2_forward` semantics.
 #include "common.h"
 
@@ -20,99 +19,132 @@ struct DcnParams {
   long npix;   // H*W
 };
 
-// bilinear sample of 8 consecutive channels, zero outside (dcn_v2_im2col_cuda.cu:25-54,180)
-__device__ __forceinline__ void sample8(const half_t* xg, int H, int W, int sp, float h_im, float w_im, float mask,
-                                        half8& out) {
-  float acc[8];
+// Fused kernel, 3x3 / stride 1 / pad 1 / dilation 1, 8 channels per deformable group.
+// One 256-thread workgroup = an 8x8 pixel tile x all 8G output channels.
+//   sampling phase: thread (pixel = tid>>3 [+32], group = tid&7) -> the 8 lanes of a pixel read
+//     one full 128-byte NHWC line per bilinear corner (coalesced), branch-free (clamped address,
+//     zeroed weight) so all corner loads of a tap are in flight together; modulated samples go
+//     to an LDS column tile of 3 taps x 8G channels per pixel (stride +16 B: conflict-free).
+//   MFMA phase: wave (mt, nt) multiplies the 32-row weight tile mt with the 32-pixel half nt,
+//     B fragments = 16-byte LDS reads (lane = pixel, k-chunk = group), 3 taps per barrier pair.
+constexpr int DCN_TPX = 8, DCN_TPY = 8, DCN_TAPS_PER_CHUNK = 3;
+
+__device__ __forceinline__ half8 sample8_bf(const half_t* xg, int H, int W, int sp, float h_im, float w_im, float mask) {
+  // dcn_v2_im2col_cuda.cu:25-54 (bilinear, zero outside) and :180 (open-interval test), branch-free
+  const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+  const float hc = fminf(fmaxf(h_im, -2.f), (float)H + 1.f), wc = fminf(fmaxf(w_im, -2.f), (float)W + 1.f);
+  const float hf = floorf(hc), wf = floorf(wc);
+  const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
+  const float lh = hc - hf, lw = wc - wf, hh = 1.f - lh, hw = 1.f - lw;
+  const bool hl = h_low >= 0 && h_low <= H - 1, hhg = h_high >= 0 && h_high <= H - 1;
+  const bool wl = w_low >= 0 && w_low <= W - 1, whg = w_high >= 0 && w_high <= W - 1;
+  const float w1 = (inside && hl && wl) ? hh * hw : 0.f, w2 = (inside && hl && whg) ? hh * lw : 0.f;
+  const float w3 = (inside && hhg && wl) ? lh * hw : 0.f, w4 = (inside && hhg && whg) ? lh * lw : 0.f;
+  const int y0 = min(max(h_low, 0), H - 1), y1 = min(max(h_high, 0), H - 1);
+  const int x0 = min(max(w_low, 0), W - 1), x1 = min(max(w_high, 0), W - 1);
+  const half8 v1 = *reinterpret_cast<const half8*>(xg + ((long)y0 * W + x0) * sp);
+  const half8 v2 = *reinterpret_cast<const half8*>(xg + ((long)y0 * W + x1) * sp);
+  const half8 v3 = *reinterpret_cast<const half8*>(xg + ((long)y1 * W + x0) * sp);
+  const half8 v4 = *reinterpret_cast<const half8*>(xg + ((long)y1 * W + x1) * sp);
+  half8 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-    const float hf = floorf(h_im), wf = floorf(w_im);
-    const int h_low = (int)hf, w_low = (int)wf;
-    const int h_high = h_low + 1, w_high = w_low + 1;
-    const float lh = h_im - hf, lw = w_im - wf;
-    const float hh = 1.f - lh, hw = 1.f - lw;
-    const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-    half8 v1 = {0, 0, 0, 0, 0, 0, 0, 0}, v2 = v1, v3 = v1, v4 = v1;
-    if (h_low >= 0 && w_low >= 0) v1 = *reinterpret_cast<const half8*>(xg + ((long)h_low * W + w_low) * sp);
-    if (h_low >= 0 && w_high <= W - 1) v2 = *reinterpret_cast<const half8*>(xg + ((long)h_low * W + w_high) * sp);
-    if (h_high <= H - 1 && w_low >= 0) v3 = *reinterpret_cast<const half8*>(xg + ((long)h_high * W + w_low) * sp);
-    if (h_high <= H - 1 && w_high <= W - 1) v4 = *reinterpret_cast<const half8*>(xg + ((long)h_high * W + w_high) * sp);
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      acc[j] = (w1 * (float)v1[j] + w2 * (float)v2[j] + w3 * (float)v3[j] + w4 * (float)v4[j]) * mask;
-  }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) out[j] = (half_t)acc[j];
+  for (int j = 0; j < 8; ++j)
+    o[j] = (half_t)((w1 * (float)v1[j] + w2 * (float)v2[j] + w3 * (float)v3[j] + w4 * (float)v4[j]) * mask);
+  return o;
 }
 
-// 3x3, stride 1, pad 1, dilation 1, 8 channels / deformable group, Cin = Cout = 8G <= 64.
-// One wave = 32 pixels x 64 output channels; 4 waves / block.
 __global__ __launch_bounds__(256) void dcn_fused_kernel(const DcnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char col[];
+  const int G = p.G;
+  const int PS = DCN_TAPS_PER_CHUNK * G * 16 + 16;       // LDS bytes per pixel (3 taps x 8G halves + pad)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, r = lane & 31;
+  const int mt = wave & 1, nt = wave >> 1;
+  const int tiles_x = (p.W + DCN_TPX - 1) / DCN_TPX;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
   const int n = blockIdx.y;
-  const long pix = ((long)blockIdx.x * 4 + wave) * 32 + r;
-  const bool valid = pix < p.npix;
-  const long pc = valid ? pix : p.npix - 1;
-  const int oy = (int)(pc / p.W), ox = (int)(pc % p.W);
-
   const half_t* xn = p.x + (long)n * p.x_sn;
-  const half_t* omp = p.om + (long)n * p.om_sn + pc * p.om_sp;
-  const int G = p.G;
-  const int steps_per_tap = G / 2;
 
-  f32x16 acc[2];
+  // ---- sampling identity: two pixels per thread (pass 0: pixels 0..31, pass 1: 32..63)
+  const int g = tid & 7;
+  const bool g_on = g < G;
+  const int gg = g_on ? g : 0;
+  int soy[2], sox[2];
+  half2v off[2][9];
+  float msk[2][9];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
-
-  const half_t* wbase = p.w + (long)lane * 8;
-  const long tile_stride = (long)9 * steps_per_tap * 512;   // halves per 32-row cout tile
-
-  for (int s2 = 0; s2 < steps_per_tap; ++s2) {
-    const int g = 2 * s2 + hh;
-    const half_t* xg = xn + g * 8;
-    // offsets of group g: channels [g*18, g*18+18) = (dh,dw) x 9 taps; mask logits at 18G + g*9 + t
-    const half_t* og = omp + g * 18;
-    const half_t* mg = omp + 18 * G + g * 9;
+  for (int ps = 0; ps < 2; ++ps) {
+    const int pl = (tid >> 3) + 32 * ps;
+    soy[ps] = ty * DCN_TPY + (pl >> 3);
+    sox[ps] = tx * DCN_TPX + (pl & 7);
+    const int cy = min(soy[ps], p.H - 1), cx = min(sox[ps], p.W - 1);
+    const half_t* omp = p.om + (long)n * p.om_sn + ((long)cy * p.W + cx) * p.om_sp;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const half2v o2 = *reinterpret_cast<const half2v*>(og + 2 * t);
-      const float ml = (float)mg[t];
-      const float mask = 1.f / (1.f + __expf(-ml));
-      const float h_im = (float)(oy - 1 + t / 3) + (float)o2[0];
-      const float w_im = (float)(ox - 1 + t % 3) + (float)o2[1];
-      half8 b;
-      sample8(xg, p.H, p.W, p.x_sp, h_im, w_im, mask, b);
-      const half_t* wp = wbase + (long)(t * steps_per_tap + s2) * 512;
-      const half8 a0 = *reinterpret_cast<const half8*>(wp);
-      const half8 a1 = *reinterpret_cast<const half8*>(wp + tile_stride);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b, acc[1], 0, 0, 0);
+      off[ps][t] = *reinterpret_cast<const half2v*>(omp + gg * 18 + 2 * t);
+      msk[ps][t] = (float)omp[18 * G + gg * 9 + t];
     }
   }
 
-  if (!valid) return;
-  half_t* yp = reinterpret_cast<half_t*>(p.y.p) + (long)n * p.y.sn + pix * p.y.sp;
+  f32x16 acc;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int steps_per_tap = G / 2;
+  const half_t* wbase = p.w + ((long)mt * 9 * steps_per_tap * 64 + lane) * 8;
+  const unsigned char* bcol = col + (nt * 32 + r) * PS + hh * 16;
+
+  for (int chunk = 0; chunk < 3; ++chunk) {
+    if (chunk > 0) __syncthreads();
+    if (g_on) {
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      const int co = mt * 32 + 8 * gq + 4 * hh;
-      if (co >= p.y.C) continue;
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + co);
-      half4 o;
+      for (int ps = 0; ps < 2; ++ps) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float v = acc[mt][4 * gq + i] + b4[i];
-        if (p.round16) v = (float)(half_t)v;
-        v = act_apply(v, p.act, p.slope);
-        o[i] = (half_t)v;
+        for (int tc = 0; tc < DCN_TAPS_PER_CHUNK; ++tc) {
+          // runtime chunk, compile-time tc: select the tap's registers without dynamic indexing
+          half2v o2 = off[ps][tc];
+          float ml = msk[ps][tc];
+          if (chunk == 1) { o2 = off[ps][3 + tc]; ml = msk[ps][3 + tc]; }
+          if (chunk == 2) { o2 = off[ps][6 + tc]; ml = msk[ps][6 + tc]; }
+          const float mask = 1.f / (1.f + __expf(-ml));
+          const float h_im = (float)(soy[ps] - 1 + chunk) + (float)o2[0];      // tap = chunk*3 + tc: dy = chunk, dx = tc
+          const float w_im = (float)(sox[ps] - 1 + tc) + (float)o2[1];
+          const half8 v = sample8_bf(xn + gg * 8, p.H, p.W, p.x_sp, h_im, w_im, mask);
+          const int pl = (tid >> 3) + 32 * ps;
+          *reinterpret_cast<half8*>(col + pl * PS + tc * G * 16 + gg * 16) = v;
+        }
       }
-      *reinterpret_cast<half4*>(yp + co) = o;
     }
+    __syncthreads();
+#pragma unroll
+    for (int tc = 0; tc < DCN_TAPS_PER_CHUNK; ++tc) {
+      const int tap = chunk * 3 + tc;
+      for (int s2 = 0; s2 < steps_per_tap; ++s2) {
+        const half8 a = *reinterpret_cast<const half8*>(wbase + (long)(tap * steps_per_tap + s2) * 512);
+        const half8 b = *reinterpret_cast<const half8*>(bcol + tc * G * 16 + s2 * 32);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+      }
+    }
+  }
+
+  const int pl = nt * 32 + r;
+  const int oy = ty * DCN_TPY + (pl >> 3), ox = tx * DCN_TPX + (pl & 7);
+  if (oy >= p.H || ox >= p.W) return;
+  half_t* yp = reinterpret_cast<half_t*>(p.y.p) + (long)n * p.y.sn + ((long)oy * p.W + ox) * p.y.sp;
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    const int co = mt * 32 + 8 * gq + 4 * hh;
+    if (co >= p.y.C) continue;
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+    half4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = acc[4 * gq + i] + b4[i];
+      if (p.round16) v = (float)(half_t)v;
+      v = act_apply(v, p.act, p.slope);
+      o[i] = (half_t)v;
+    }
+    *reinterpret_cast<half4*>(yp + co) = o;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -203,7 +235,7 @@ extern "C" int tdvc_dcn_fused(const tdvc_dcn_desc* d, void* stream) {
   TDVC_CHECK(d, "tdvc_dcn_fused: null descriptor");
   TDVC_CHECK(fmap_ok16(d->x) && fmap_ok16(d->om) && fmap_ok16(d->y), "tdvc_dcn_fused: fmaps must be fp16, C/sp %% 8, aligned");
   const int G = d->groups;
-  TDVC_CHECK(G >= 2 && G <= 8 && (G % 2) == 0, "tdvc_dcn_fused: groups=%d unsupported (even, 2..8)", G);
+  TDVC_CHECK(G == 8, "tdvc_dcn_fused: groups=%d unsupported (the fused kernel is built for the hot-path geometry: 8 groups x 8 channels; use tdvc_dcn_v2_forward_f32 otherwise)", G);
   TDVC_CHECK(d->x.C == 8 * G && d->y.C == 8 * G, "tdvc_dcn_fused: needs Cin = Cout = 8*groups (8 channels per group)");
   TDVC_CHECK(d->om.C >= 27 * G, "tdvc_dcn_fused: offset/mask fmap needs >= 27*groups channels");
   TDVC_CHECK(d->x.N == d->y.N && d->x.N == d->om.N && d->x.H == d->y.H && d->x.W == d->y.W && d->om.H == d->x.H && d->om.W == d->x.W,
@@ -216,8 +248,9 @@ extern "C" int tdvc_dcn_fused(const tdvc_dcn_desc* d, void* stream) {
   p.w = reinterpret_cast<const half_t*>(d->w); p.bias = d->bias;
   p.G = G; p.act = d->act; p.slope = d->slope; p.round16 = d->round_before_act;
   p.npix = (long)d->x.H * d->x.W;
-  dim3 grid((unsigned)((p.npix + 127) / 128), d->x.N);
-  hipLaunchKernelGGL(dcn_fused_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  dim3 grid((unsigned)(((d->x.W + DCN_TPX - 1) / DCN_TPX) * ((d->x.H + DCN_TPY - 1) / DCN_TPY)), d->x.N);
+  const size_t lds = (size_t)64 * (DCN_TAPS_PER_CHUNK * G * 16 + 16);
+  hipLaunchKernelGGL(dcn_fused_kernel, grid, dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
   return tdvc_launch_status("tdvc_dcn_fused");
 }
 

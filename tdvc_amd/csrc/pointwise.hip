@@ -166,15 +166,25 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(FMap x, float* partial
   }
 }
 
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* partial, int nblocks, float inv_count, int C, int Cmid,
+__global__ __launch_bounds__(1024) void se_gate_kernel(const float* partial, int nblocks, float inv_count, int C, int Cmid,
                                                        const float* w1, const float* b1, const float* w2, const float* b2,
                                                        float* gate) {
   __shared__ float mean[256];
   __shared__ float mid[32];
+  __shared__ float part[1024];
   const int n = blockIdx.x, tid = threadIdx.x;
+  // fixed-order two-level sum of the partials: `ways` threads per channel, then a serial tail
+  const int ways = 1024 / C < 1 ? 1 : (1024 / C > 1024 / 32 ? 32 : 1024 / C);
+  for (int i = tid; i < C * ways; i += 1024) {
+    const int c = i % C, wy = i / C;
+    float s = 0.f;
+    for (int b = wy; b < nblocks; b += ways) s += partial[((long)n * nblocks + b) * C + c];
+    part[wy * C + c] = s;
+  }
+  __syncthreads();
   if (tid < C) {
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partial[((long)n * nblocks + b) * C + tid];
+    for (int wy = 0; wy < ways; ++wy) s += part[wy * C + tid];
     mean[tid] = s * inv_count;
   }
   __syncthreads();
@@ -622,7 +632,7 @@ extern "C" int tdvc_channel_sum(const tdvc_fmap* x, float* partial, int nblocks,
 extern "C" int tdvc_se_gate(const float* partial, int nblocks, float inv_count, int N, int C, int Cmid,
                             const float* w1, const float* b1, const float* w2, const float* b2, float* gate, void* stream) {
   TDVC_CHECK(partial && w1 && b1 && w2 && b2 && gate && C <= 256 && Cmid <= 32 && N >= 1, "tdvc_se_gate: bad arguments");
-  hipLaunchKernelGGL(se_gate_kernel, dim3(N), dim3(256), 0, ST(stream), partial, nblocks, inv_count, C, Cmid, w1, b1, w2, b2, gate);
+  hipLaunchKernelGGL(se_gate_kernel, dim3(N), dim3(1024), 0, ST(stream), partial, nblocks, inv_count, C, Cmid, w1, b1, w2, b2, gate);
   return tdvc_launch_status("tdvc_se_gate");
 }
 
