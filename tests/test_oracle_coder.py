@@ -1,0 +1,85 @@
+"""CPU: self-consistency of the entropy-model restatement (parity unpinned, see oracle/tdvc_ref/coder.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.tdvc_ref import coder as oc
+from tdvc_amd.synth import fill_parameters
+
+
+def test_pmf_to_quantized_cdf_properties():
+    rng = np.random.default_rng(0)
+    for n in (3, 17, 64):
+        p = rng.random(n) ** 4
+        p[rng.integers(0, n, 3)] = 1e-12          # nearly-empty bins must still get freq >= 1
+        p = p / p.sum()
+        cdf = oc.pmf_to_quantized_cdf(p.tolist(), 16)
+        assert cdf[0] == 0 and cdf[-1] == 65536 and len(cdf) == n + 1
+        assert all(b > a for a, b in zip(cdf, cdf[1:]))
+
+
+def test_rans_roundtrip_with_bypass():
+    rng = np.random.default_rng(1)
+    pmfs = [np.array([0.6, 0.3, 0.05, 0.05]), np.array([0.1, 0.1, 0.5, 0.2, 0.05, 0.05])]
+    cdfs, sizes, offsets = [], [], [-1, -2]
+    width = 8
+    for p in pmfs:
+        c = oc.pmf_to_quantized_cdf(p.tolist(), 16)
+        sizes.append(len(c))
+        cdfs.append(c + [0] * (width - len(c)))
+    idx = rng.integers(0, 2, 5000).tolist()
+    syms = []
+    for i in idx:
+        n = sizes[i] - 2                       # symbols offsets[i] .. offsets[i]+n-1 are in-table
+        s = int(rng.integers(offsets[i] - 40, offsets[i] + n + 40)) if rng.random() < 0.05 else int(rng.integers(offsets[i], offsets[i] + n))
+        syms.append(s)
+    data = oc.rans_encode(syms, idx, cdfs, sizes, offsets)
+    assert len(data) % 4 == 0
+    assert oc.RansDecoder(data).decode(idx, cdfs, sizes, offsets) == syms
+
+
+@pytest.fixture(scope="module")
+def small_coder():
+    torch.manual_seed(0)
+    m = oc.MVCoder(N=128).eval()
+    h = torch.nn.Module(); h.add_module("mvCoder", m); fill_parameters(h)
+    m.update(force=True)
+    return m
+
+
+def test_tables(small_coder):
+    m = small_coder
+    eb, gc = m.entropy_bottleneck, m.gaussian_conditional
+    assert eb._quantized_cdf.shape[0] == 128 and gc._quantized_cdf.shape[0] == 64
+    for t, ln in ((eb._quantized_cdf, eb._cdf_length), (gc._quantized_cdf, gc._cdf_length)):
+        for i in range(t.shape[0]):
+            row = t[i, : int(ln[i])].tolist()
+            assert row[0] == 0 and row[-1] == 65536 and all(b > a for a, b in zip(row, row[1:]))
+    # scale table + index rule
+    s = torch.tensor([0.05, 0.11, 0.5, 300.0])
+    idx = gc.build_indexes(s)
+    assert idx.tolist()[0] == 0 and idx.tolist()[-1] == 63
+
+
+def test_compress_decompress_roundtrip(small_coder):
+    m = small_coder
+    x = torch.randn(1, 64, 64, 64, generator=torch.Generator().manual_seed(3)) * 0.5
+    enc = m.compress(x)
+    dec = m.decompress(enc["strings"], enc["shape"])
+    y_hat_enc = enc["_debug"][0]["y_hat"]
+    assert torch.equal(dec["y_hat"], y_hat_enc), "decoder must reproduce the encoder's y_hat exactly"
+    assert len(enc["strings"][0][0]) > 8 and len(enc["strings"][1][0]) >= 8
+    # forward pass: rate estimate is close to the actual coded size (same model, eval quantisation)
+    with torch.no_grad():
+        out = m(x)
+    bits_est = float(sum((-torch.log2(l)).sum() for l in out["likelihoods"].values()))
+    bits_act = 8.0 * (len(enc["strings"][0][0]) + len(enc["strings"][1][0]))
+    assert 0.5 * bits_act < bits_est < 2.0 * bits_act + 512, (bits_est, bits_act)
+
+
+def test_forward_train_mode_runs(small_coder):
+    m = small_coder
+    m.train()
+    out = m(torch.randn(1, 64, 64, 64) * 0.5)
+    assert out["x_hat"].shape == (1, 64, 64, 64) and float(m.aux_loss()) > 0
+    m.eval()
