@@ -1,0 +1,170 @@
+// Shared between the MFMA conv kernels: launch parameters and the fused epilogue.
+#pragma once
+#include "common.h"
+
+namespace convk {
+
+struct ConvParams {
+  const half_t* x; long x_sn; int x_sp; int H, W, Cin;
+  const half_t* w; const float* bias;
+  FMap y; int Ho, Wo; int cout;
+  FMap aux; FMap res; FMap res2;
+  int ntaps, kh, kw, pad;
+  int nchunks, steps;   // steps per chunk
+  int square, gdn, act; float slope; int round16, out_mode;
+  int tiles_x;
+  int8_t tap_dy[TDVC_MAX_TAPS], tap_dx[TDVC_MAX_TAPS];
+};
+
+
+// Epilogue for 4 consecutive output channels co..co+3 of output pixel (oy, ox) of image n:
+// bias -> GDN -> fp16 rounding (DCN quirk) -> activation -> residual(s) -> store (NHWC fp16 / fp32,
+// PixelShuffle(2), planar fp32).
+__device__ __forceinline__ void epilogue4(const ConvParams& p, int n, int oy, int ox, int co, float v[4]) {
+  if (p.bias) {
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += b4[i];
+  }
+  // output geometry
+  int py = oy, px = ox, pc = co, PW = p.Wo;
+  if (p.out_mode == TDVC_OUT_SHUFFLE2) {
+    const int cq = p.cout >> 2;            // channels after the shuffle
+    const int sub = co / cq;               // host permutes rows: packed = (i*2+j)*cq + c
+    pc = co - sub * cq;
+    py = 2 * oy + (sub >> 1);
+    px = 2 * ox + (sub & 1);
+    PW = 2 * p.Wo;
+  }
+  if (p.gdn) {
+    const half_t* ap = reinterpret_cast<const half_t*>(p.aux.p) + (long)n * p.aux.sn + ((long)oy * p.Wo + ox) * p.aux.sp + co;
+    const half4 a4 = *reinterpret_cast<const half4*>(ap);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      v[i] = (float)a4[i] * (p.gdn == TDVC_GDN_FWD ? rsqrtf(v[i]) : sqrtf(v[i]));
+  }
+  if (p.round16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)(half_t)v[i];
+  }
+  if (p.act) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = act_apply(v[i], p.act, p.slope);
+  }
+  const long opix = (long)py * PW + px;
+  if (p.res.p) {
+    if (p.res.f32) {
+      const float* rp = reinterpret_cast<const float*>(p.res.p) + (long)n * p.res.sn + opix * p.res.sp + pc;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (pc + i < p.res.C) v[i] += rp[i];
+    } else if (pc < p.res.C) {
+      const half4 r4 = *reinterpret_cast<const half4*>(reinterpret_cast<const half_t*>(p.res.p) + (long)n * p.res.sn + opix * p.res.sp + pc);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += (float)r4[i];
+    }
+  }
+  if (p.res2.p && pc < p.res2.C) {
+    const half4 r4 = *reinterpret_cast<const half4*>(reinterpret_cast<const half_t*>(p.res2.p) + (long)n * p.res2.sn + opix * p.res2.sp + pc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += (float)r4[i];
+  }
+  if (p.out_mode == TDVC_OUT_NCHW_F32) {
+    float* yp = reinterpret_cast<float*>(p.y.p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (co + i < p.cout) yp[(((long)n * p.cout + co + i) * p.Ho + oy) * p.Wo + ox] = v[i];
+  } else if (p.y.f32) {
+    float* yp = reinterpret_cast<float*>(p.y.p) + (long)n * p.y.sn + opix * p.y.sp + pc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (pc + i < p.y.C) yp[i] = v[i];
+  } else if (pc < p.y.C) {
+    half4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (half_t)v[i];
+    *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.y.p) + (long)n * p.y.sn + opix * p.y.sp + pc) = o;
+  }
+}
+
+// Transposed "simple" epilogue shared by conv_mfma_v2/v3/v4 (fp16 NHWC output, bias, none / ReLU /
+// LeakyReLU via a slope select, up to two fp16 residuals).  One pass = one output row of 32 pixels x 64
+// channels of this wave: bias + activation in the MFMA layout (4 consecutive channels per lane), fp16
+// through a wave-private LDS region `ew` (32 x 144 B), then every lane owns 8 consecutive channels of a
+// pixel, so residuals and the output move as full 128-byte lines (8 lanes x 16 B per pixel).  All
+// residual loads of a pass are issued before any is consumed (one memory round trip per pass).
+template <int NTX>
+__device__ __forceinline__ void epilogue_simple_rows(const ConvParams& p, f32x16 (&acc)[2][NTX], const float* bias64,
+                                                     unsigned char* ew, int n, int cbase, int oy_first, int ox_first,
+                                                     int lane, bool zero_acc) {
+  constexpr int EPS = 144;
+  const int hh = lane >> 5, r = lane & 31;
+  const int chunk = lane & 7, prow = lane >> 3;
+  const int co = cbase + chunk * 8;
+  const bool ch_ok = co < p.y.C;
+  const bool has1 = p.res.p != nullptr, has2 = p.res2.p != nullptr;
+#pragma unroll
+  for (int nt = 0; nt < NTX; ++nt) {
+    const int oy = oy_first + nt;
+    const bool row_ok = oy < p.Ho && ch_ok;
+    // residual loads first (clamped, unconditional within the uniform branch)
+    half8 r1[4], r2[4];
+    long opix[4];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ox = ox_first + k * 8 + prow;
+      ok[k] = row_ok && ox < p.Wo;
+      opix[k] = ok[k] ? (long)oy * p.Wo + ox : 0;
+    }
+    if (has1) {
+      const half_t* rb = reinterpret_cast<const half_t*>(p.res.p) + (long)n * p.res.sn + (ch_ok ? co : 0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r1[k] = *reinterpret_cast<const half8*>(rb + opix[k] * p.res.sp);
+    }
+    if (has2) {
+      const half_t* rb = reinterpret_cast<const half_t*>(p.res2.p) + (long)n * p.res2.sn + (ch_ok ? co : 0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r2[k] = *reinterpret_cast<const half8*>(rb + opix[k] * p.res2.sp);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cl = mt * 32 + 8 * g + 4 * hh;
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias64 + cl);
+        half4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = acc[mt][nt][4 * g + i] + b4[i];
+          if (zero_acc) acc[mt][nt][4 * g + i] = 0.f;
+          v = v > 0.f ? v : v * p.slope;
+          o[i] = (half_t)v;
+        }
+        *reinterpret_cast<half4*>(ew + r * EPS + cl * 2) = o;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      half8 h = *reinterpret_cast<const half8*>(ew + (k * 8 + prow) * EPS + chunk * 16);
+      if (has1 || has2) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+        if (has1) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += (float)r1[k][j];
+        }
+        if (has2) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += (float)r2[k][j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
+      }
+      if (ok[k]) *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.y.p) + (long)n * p.y.sn + opix[k] * p.y.sp + co) = h;
+    }
+  }
+}
+
+}  // namespace convk

@@ -15,23 +15,19 @@
 // slots (conflict-free).  Stride-2 convs de-interleave columns by parity while staging so the
 // same holds.  Weights are pre-packed on the host in MFMA fragment order: one wave-wide 1 KiB
 // coalesced global_load_dwordx4 per fragment, served from L2 (a layer's weights are <= 0.6 MB).
-#include "common.h"
+#include "conv_common.h"
+
+using convk::ConvParams;
+int launch_conv_v2(const ConvParams& p, int ntiles, int cout_blocks, int N, hipStream_t st);
+bool conv_v2_eligible(const tdvc_conv_desc* d, int Ho, int Wo);
+int launch_conv_v3(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
+bool conv_v3_eligible(const tdvc_conv_desc* d, int Ho, int Wo);
+int launch_conv_v4(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
+bool conv_v4_eligible(const tdvc_conv_desc* d, int Ho, int Wo);
 
 namespace {
 
 constexpr int TH = 8, TW = 32;
-
-struct ConvParams {
-  const half_t* x; long x_sn; int x_sp; int H, W, Cin;
-  const half_t* w; const float* bias;
-  FMap y; int Ho, Wo; int cout;
-  FMap aux; FMap res; FMap res2;
-  int ntaps, kh, kw, pad;
-  int nchunks, steps;   // steps per chunk
-  int square, gdn, act; float slope; int round16, out_mode;
-  int tiles_x;
-  int8_t tap_dy[TDVC_MAX_TAPS], tap_dx[TDVC_MAX_TAPS];
-};
 
 template <int CK8, int MT, int STRIDE>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
@@ -147,70 +143,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = acc[mt][nt][4 * g + i];
-        if (p.bias) {
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + co);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] += b4[i];
-        }
-        // output geometry
-        int py = oy, px = ox, pc = co, PW = p.Wo;
-        if (p.out_mode == TDVC_OUT_SHUFFLE2) {
-          const int cq = p.cout >> 2;            // channels after the shuffle
-          const int sub = co / cq;               // host permutes rows: packed = (i*2+j)*cq + c
-          pc = co - sub * cq;
-          py = 2 * oy + (sub >> 1);
-          px = 2 * ox + (sub & 1);
-          PW = 2 * p.Wo;
-        }
-        if (p.gdn) {
-          const half_t* ap = reinterpret_cast<const half_t*>(p.aux.p) + (long)n * p.aux.sn + ((long)oy * p.Wo + ox) * p.aux.sp + co;
-          const half4 a4 = *reinterpret_cast<const half4*>(ap);
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            v[i] = (float)a4[i] * (p.gdn == TDVC_GDN_FWD ? rsqrtf(v[i]) : sqrtf(v[i]));
-        }
-        if (p.round16) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = (float)(half_t)v[i];
-        }
-        if (p.act) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = act_apply(v[i], p.act, p.slope);
-        }
-        const long opix = (long)py * PW + px;
-        if (p.res.p) {
-          if (p.res.f32) {
-            const float* rp = reinterpret_cast<const float*>(p.res.p) + (long)n * p.res.sn + opix * p.res.sp + pc;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (pc + i < p.res.C) v[i] += rp[i];
-          } else if (pc < p.res.C) {
-            const half4 r4 = *reinterpret_cast<const half4*>(reinterpret_cast<const half_t*>(p.res.p) + (long)n * p.res.sn + opix * p.res.sp + pc);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] += (float)r4[i];
-          }
-        }
-        if (p.res2.p && pc < p.res2.C) {
-          const half4 r4 = *reinterpret_cast<const half4*>(reinterpret_cast<const half_t*>(p.res2.p) + (long)n * p.res2.sn + opix * p.res2.sp + pc);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] += (float)r4[i];
-        }
-        if (p.out_mode == TDVC_OUT_NCHW_F32) {
-          float* yp = reinterpret_cast<float*>(p.y.p);
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (co + i < p.cout) yp[(((long)n * p.cout + co + i) * p.Ho + oy) * p.Wo + ox] = v[i];
-        } else if (p.y.f32) {
-          float* yp = reinterpret_cast<float*>(p.y.p) + (long)n * p.y.sn + opix * p.y.sp + pc;
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (pc + i < p.y.C) yp[i] = v[i];
-        } else if (pc < p.y.C) {
-          half4 o;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) o[i] = (half_t)v[i];
-          *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.y.p) + (long)n * p.y.sn + opix * p.y.sp + pc) = o;
-        }
+        convk::epilogue4(p, n, oy, ox, co, v);
       }
     }
   }
@@ -368,6 +301,9 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
   p.tiles_x = tiles_x;
   const int tiles = cout_tiles(d->cout);
   const int mt = tiles == 1 ? 1 : 2;
+  if (conv_v4_eligible(d, Ho, Wo)) return launch_conv_v4(p, tiles / 2, d->x.N, reinterpret_cast<hipStream_t>(stream));
+  if (conv_v3_eligible(d, Ho, Wo)) return launch_conv_v3(p, tiles / 2, d->x.N, reinterpret_cast<hipStream_t>(stream));
+  if (conv_v2_eligible(d, Ho, Wo)) return launch_conv_v2(p, 0, tiles / 2, d->x.N, reinterpret_cast<hipStream_t>(stream));
   dim3 grid(tiles_x * tiles_y, tiles / mt, d->x.N);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   switch (ck8) {

@@ -139,8 +139,11 @@ def pack_conv(weight: torch.Tensor, bias: torch.Tensor | None, stride=1, pad=0, 
         taps = [(dy, dx) for dy in range(kh) for dx in range(kw)]
     lib = L.lib()
     if ck is None:
-        ck = lib.tdvc_conv_plan(cin, kh, kw, stride)
-        L.check(0 if ck > 0 else ck, "conv_plan")
+        if stride == 1 and len(taps) >= 2 and cin >= 32 and cout >= 64:
+            ck = 32          # the persistent pipelined kernel (conv_mfma_v2) streams 32-channel chunks
+        else:
+            ck = lib.tdvc_conv_plan(cin, kh, kw, stride)
+            L.check(0 if ck > 0 else ck, "conv_plan")
     nbytes = lib.tdvc_conv_packed_bytes(cout, cin, len(taps), ck)
     assert nbytes > 0
     dst = np.zeros(nbytes // 2, dtype=np.uint16)
@@ -196,7 +199,11 @@ def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, 
         e0.record()
         L.check(L.lib().tdvc_conv2d(C.byref(d), _stream()), "conv2d")
         e1.record()
-        PROFILE.append(dict(kernel=f"conv_mfma<{pc.ck // 8},{1 if pc.cout <= 32 else 2},{pc.stride}>", e0=e0, e1=e1,
+        v2 = pc.ck == 32 and pc.stride == 1 and len(pc.taps) >= 2 and pc.cout >= 64 and Ho * Wo >= 2048
+        v3 = v2 and len(pc.taps) <= 9 and pc.kh <= 3 and pc.kw <= 3
+        v4 = v3 and Ho * Wo >= 8192 and 256 + 18 * 34 * 80 + ((x.C + 31) // 32) * len(pc.taps) * 4096 <= 150 * 1024
+        PROFILE.append(dict(kernel="conv_mfma_v4" if v4 else "conv_mfma_v3" if v3 else "conv_mfma_v2" if v2 else f"conv_mfma<{pc.ck // 8},{1 if pc.cout <= 32 else 2},{pc.stride}>",
+                            e0=e0, e1=e1,
                             flops=2.0 * x.N * Ho * Wo * pc.cout * x.C * len(pc.taps),
                             flops_real=2.0 * x.N * Ho * Wo * pc.cout * pc.cin_real * len(pc.taps),
                             bytes=2.0 * x.N * (x.H * x.W * x.C + Ho * Wo * pc.cout * (4 if pc.shuffle else 1) / (4 if pc.shuffle else 1))))

@@ -169,3 +169,65 @@ def test_conv_errors():
     bad = ops.FM.empty(1, 8, 8, 64)
     with pytest.raises(TdvcHipError):
         ops.conv(x, pc, out=bad)
+
+
+# ---- shapes large enough for the persistent pipelined kernel (conv_mfma_v2) -------------------
+V2_CASES = [
+    # name, N, cin, cout, k, H, W
+    ("v2_3x3_64_64", 1, 64, 64, 3, 70, 100),
+    ("v2_3x3_64_64_tileedge", 1, 64, 64, 3, 64, 96),
+    ("v2_3x3_128_64", 2, 128, 64, 3, 50, 70),
+    ("v2_3x3_64_216", 1, 64, 216, 3, 48, 80),
+    ("v2_3x3_128_128", 1, 128, 128, 3, 33, 65),
+    ("v2_7x7_32_64", 1, 32, 64, 7, 40, 70),
+    ("v2_3x3_40_64", 1, 40, 64, 3, 48, 64),       # Cin not a multiple of the 32-channel chunk
+    ("v2_3x3_192_256", 1, 192, 256, 3, 40, 60),
+    ("v2_3x3_64_64_many_tiles", 1, 64, 64, 3, 272, 480),   # > 256 tiles: several tiles per workgroup
+]
+
+
+@pytest.mark.parametrize("case", V2_CASES, ids=[c[0] for c in V2_CASES])
+def test_conv_v2(case, report):
+    ops = _ops()
+    name, N, cin, cout, k, H, W = case
+    x = rnd16(randn(N, cin, H, W, seed=41))
+    w = rnd16(randn(cout, cin, k, k, seed=42) * (1.0 / (cin * k * k) ** 0.5))
+    b = randn(cout, seed=43) * 0.1
+    r1 = rnd16(randn(N, cout, H, W, seed=44))
+    ref = F.leaky_relu(F.conv2d(x, w, b, padding=k // 2), 0.1) + r1
+    pc = ops.pack_conv(w, b, stride=1, pad=k // 2)
+    assert pc.ck == 32
+    y = ops.conv(to_fm(x, ops), pc, act=ops.ACT_LRELU, slope=0.1, res=to_fm(r1, ops))
+    assert_close(fm_to_cpu(y, cout), ref, RT, AT, f"conv {name}", report)
+
+
+def test_conv_v2_masked_shuffle_slices(report):
+    ops = _ops()
+    # masked 5x5 context conv on a latent-sized map
+    x = rnd16(randn(1, 128, 68, 120, seed=45))
+    w = rnd16(randn(256, 128, 5, 5, seed=46) * 0.02)
+    b = randn(256, seed=47) * 0.1
+    mask = torch.ones_like(w)
+    mask[:, :, 2, 2:] = 0
+    mask[:, :, 3:] = 0
+    taps = [(dy, dx) for dy in range(5) for dx in range(5) if dy < 2 or (dy == 2 and dx < 2)]
+    y = ops.conv(to_fm(x, ops), ops.pack_conv(w, b, stride=1, pad=2, taps=taps))
+    assert_close(fm_to_cpu(y), F.conv2d(x, w * mask, b, padding=2), RT, AT, "v2 masked 5x5", report)
+    # sub-pixel conv with residual at the shuffled resolution
+    x = rnd16(randn(1, 128, 48, 64, seed=48))
+    w = rnd16(randn(512, 128, 3, 3, seed=49) * 0.03)
+    b = randn(512, seed=50) * 0.1
+    r = rnd16(randn(1, 128, 96, 128, seed=51))
+    ref = F.leaky_relu(F.pixel_shuffle(F.conv2d(x, w, b, padding=1), 2), 0.01) + r
+    y = ops.conv(to_fm(x, ops), ops.pack_conv(w, b, stride=1, pad=1, shuffle=True), act=ops.ACT_LRELU, slope=0.01, res=to_fm(r, ops))
+    assert_close(fm_to_cpu(y), ref, RT, AT, "v2 subpel 128->128", report)
+    # frames as channel slices (Conv3d(1,3,3)) with residual buffer
+    B, T, H, W = 1, 4, 48, 64
+    x = rnd16(randn(B, T * 64, H, W, seed=52))
+    rr = rnd16(randn(B, T * 64, H, W, seed=53))
+    w = rnd16(randn(64, 64, 3, 3, seed=54) * 0.05)
+    b = randn(64, seed=55) * 0.1
+    src, dst, rb = to_fm(x, ops), ops.FM.zeros(B, H, W, T * 64), to_fm(rr, ops)
+    ops.conv(src.as_slices(0, T, 64), ops.pack_conv(w, b, stride=1, pad=1), out=dst.as_slices(0, T, 64), res=rb.as_slices(0, T, 64))
+    ref = torch.cat([F.conv2d(x[:, t * 64:(t + 1) * 64], w, b, padding=1) for t in range(T)], 1) + rr
+    assert_close(fm_to_cpu(dst), ref, RT, AT, "v2 frame slices + residual", report)

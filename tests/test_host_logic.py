@@ -73,7 +73,7 @@ def test_pack_conv_host_options():
     pc = ops.pack_conv(w, torch.randn(16), stride=1, pad=1, device="cpu")
     assert pc.cin == 8 and pc.cin_real == 6 and pc.ck == 8 and pc.bias.numel() == 32 and len(pc.taps) == 9
     pc = ops.pack_conv(torch.randn(512, 128, 3, 3), None, stride=1, pad=1, shuffle=True, device="cpu")
-    assert pc.shuffle and pc.cout == 512 and pc.bias.numel() == 512
+    assert pc.shuffle and pc.cout == 512 and pc.bias.numel() == 512 and pc.ck == 32
     from tdvc_amd.model.coder import MaskedConv2d
     mc = MaskedConv2d(8, 16, kernel_size=5, padding=2)
     taps = mc.live_taps()
