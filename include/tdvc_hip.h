@@ -70,6 +70,11 @@ typedef struct {
   tdvc_fmap res;          /* residual added AFTER the activation, at output coordinates; p==NULL: none */
   tdvc_fmap res2;         /* optional second residual (fp16), same rules */
   int32_t out_mode;
+  int32_t s2d;            /* 1: `x` is read through a 2x2 space-to-depth view: the virtual input is
+                             (H/2, W/2, 4C) with channel q*C + c = pixel (2Y + q/2, 2X + q%2), channel c.
+                             A 3x3 stride-2 pad-1 conv becomes a 2x2 stride-1 conv (kh=kw=2, pad=1 on the
+                             top/left only) over that view; weights are packed for the virtual conv
+                             (tdvc_amd/ops.py::pack_conv(s2d=True)).  Needs H, W even and C % 32 == 0. */
 } tdvc_conv_desc;
 
 /* ---------------------------------------------------------------- library */

@@ -13,6 +13,8 @@ struct ConvParams {
   int nchunks, steps;   // steps per chunk
   int square, gdn, act; float slope; int round16, out_mode;
   int tiles_x;
+  int simple;           // host decision: transposed fast epilogue (conv_is_simple)
+  int s2d, Corig;       // space-to-depth view of a stride-2 conv (v3 only): Corig = channels per parity
   int8_t tap_dy[TDVC_MAX_TAPS], tap_dx[TDVC_MAX_TAPS];
 };
 
@@ -87,12 +89,29 @@ __device__ __forceinline__ void epilogue4(const ConvParams& p, int n, int oy, in
   }
 }
 
-// Transposed "simple" epilogue shared by conv_mfma_v2/v3/v4 (fp16 NHWC output, bias, none / ReLU /
-// LeakyReLU via a slope select, up to two fp16 residuals).  One pass = one output row of 32 pixels x 64
-// channels of this wave: bias + activation in the MFMA layout (4 consecutive channels per lane), fp16
+// Which layers take the transposed epilogue below (everything else uses epilogue4).
+inline bool conv_is_simple(const ConvParams& p) {
+  const bool shuf = p.out_mode == TDVC_OUT_SHUFFLE2;
+  if (!(p.out_mode == TDVC_OUT_NHWC || shuf) || p.y.f32 || p.round16 || !p.bias) return false;
+  if (p.gdn ? p.act != TDVC_ACT_NONE : !(p.act == TDVC_ACT_NONE || p.act == TDVC_ACT_RELU || p.act == TDVC_ACT_LRELU)) return false;
+  if (p.res.p && (p.res.f32 || p.res.C < p.y.C)) return false;
+  if (p.res2.p && p.res2.C < p.y.C) return false;
+  if (shuf && (((p.cout >> 2) % 64) != 0 || p.gdn)) return false;
+  if (p.gdn && (p.aux.C < p.y.C || shuf)) return false;
+  return true;
+}
+// slope that turns `v > 0 ? v : v * slope` into none / ReLU / LeakyReLU
+inline float conv_simple_slope(const ConvParams& p) {
+  return p.act == TDVC_ACT_NONE ? 1.f : (p.act == TDVC_ACT_RELU ? 0.f : p.slope);
+}
+
+// Transposed "simple" epilogue shared by conv_mfma_v2/v3/v4: fp16 NHWC output (optionally through
+// PixelShuffle(2)), bias, none / ReLU / LeakyReLU via a slope select, GDN / inverse GDN
+// (aux * rsqrt(v) | aux * sqrt(v)), up to two fp16 residuals.  One pass = one output row of 32 pixels x
+// 64 channels of this wave: bias + activation in the MFMA layout (4 consecutive channels per lane), fp16
 // through a wave-private LDS region `ew` (32 x 144 B), then every lane owns 8 consecutive channels of a
-// pixel, so residuals and the output move as full 128-byte lines (8 lanes x 16 B per pixel).  All
-// residual loads of a pass are issued before any is consumed (one memory round trip per pass).
+// pixel, so aux / residuals / output move as full 128-byte lines (8 lanes x 16 B per pixel).  All loads
+// of a pass are issued before any is consumed (one memory round trip per pass).
 template <int NTX>
 __device__ __forceinline__ void epilogue_simple_rows(const ConvParams& p, f32x16 (&acc)[2][NTX], const float* bias64,
                                                      unsigned char* ew, int n, int cbase, int oy_first, int ox_first,
@@ -101,29 +120,43 @@ __device__ __forceinline__ void epilogue_simple_rows(const ConvParams& p, f32x16
   const int hh = lane >> 5, r = lane & 31;
   const int chunk = lane & 7, prow = lane >> 3;
   const int co = cbase + chunk * 8;
-  const bool ch_ok = co < p.y.C;
-  const bool has1 = p.res.p != nullptr, has2 = p.res2.p != nullptr;
+  const bool has1 = p.res.p != nullptr, has2 = p.res2.p != nullptr, gdn = p.gdn != 0;
+  // output geometry: plain NHWC or PixelShuffle(2) (host permutes rows: packed = (i*2+j)*cq + c)
+  int pc = co, sub_y = 0, sub_x = 0, mul = 1, PW = p.Wo;
+  if (p.out_mode == TDVC_OUT_SHUFFLE2) {
+    const int cq = p.cout >> 2;
+    const int sub = co / cq;
+    pc = co - sub * cq;
+    sub_y = sub >> 1; sub_x = sub & 1; mul = 2; PW = 2 * p.Wo;
+  }
+  const bool ch_ok = pc < p.y.C && co < ((p.cout + 63) & ~63);
 #pragma unroll
   for (int nt = 0; nt < NTX; ++nt) {
     const int oy = oy_first + nt;
     const bool row_ok = oy < p.Ho && ch_ok;
-    // residual loads first (clamped, unconditional within the uniform branch)
-    half8 r1[4], r2[4];
-    long opix[4];
+    half8 r0[4], r1[4], r2[4];
+    long opix[4], apix[4];
     bool ok[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int ox = ox_first + k * 8 + prow;
       ok[k] = row_ok && ox < p.Wo;
-      opix[k] = ok[k] ? (long)oy * p.Wo + ox : 0;
+      opix[k] = ok[k] ? (long)(mul * oy + sub_y) * PW + (mul * ox + sub_x) : 0;
+      apix[k] = ok[k] ? (long)oy * p.Wo + ox : 0;
+    }
+    const int pcc = ch_ok ? pc : 0;
+    if (gdn) {
+      const half_t* ab = reinterpret_cast<const half_t*>(p.aux.p) + (long)n * p.aux.sn + (ch_ok ? co : 0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r0[k] = *reinterpret_cast<const half8*>(ab + apix[k] * p.aux.sp);
     }
     if (has1) {
-      const half_t* rb = reinterpret_cast<const half_t*>(p.res.p) + (long)n * p.res.sn + (ch_ok ? co : 0);
+      const half_t* rb = reinterpret_cast<const half_t*>(p.res.p) + (long)n * p.res.sn + pcc;
 #pragma unroll
       for (int k = 0; k < 4; ++k) r1[k] = *reinterpret_cast<const half8*>(rb + opix[k] * p.res.sp);
     }
     if (has2) {
-      const half_t* rb = reinterpret_cast<const half_t*>(p.res2.p) + (long)n * p.res2.sn + (ch_ok ? co : 0);
+      const half_t* rb = reinterpret_cast<const half_t*>(p.res2.p) + (long)n * p.res2.sn + pcc;
 #pragma unroll
       for (int k = 0; k < 4; ++k) r2[k] = *reinterpret_cast<const half8*>(rb + opix[k] * p.res2.sp);
     }
@@ -147,10 +180,14 @@ __device__ __forceinline__ void epilogue_simple_rows(const ConvParams& p, f32x16
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       half8 h = *reinterpret_cast<const half8*>(ew + (k * 8 + prow) * EPS + chunk * 16);
-      if (has1 || has2) {
+      if (gdn || has1 || has2) {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+        if (gdn) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (float)r0[k][j] * (p.gdn == TDVC_GDN_FWD ? rsqrtf(v[j]) : sqrtf(v[j]));
+        }
         if (has1) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += (float)r1[k][j];
@@ -162,7 +199,7 @@ __device__ __forceinline__ void epilogue_simple_rows(const ConvParams& p, f32x16
 #pragma unroll
         for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
       }
-      if (ok[k]) *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.y.p) + (long)n * p.y.sn + opix[k] * p.y.sp + co) = h;
+      if (ok[k]) *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.y.p) + (long)n * p.y.sn + opix[k] * p.y.sp + pc) = h;
     }
   }
 }

@@ -130,6 +130,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   }
 
   // ---- epilogue ------------------------------------------------------------------------------
+  if constexpr (MT == 2) {
+    if (p.simple) {       // transposed full-line stores through LDS (the staging tile is dead now)
+      __syncthreads();
+      convk::epilogue_simple_rows<2>(p, acc, p.bias + cb * 64, tile + wave * (32 * 144), n, cb * 64,
+                                     ty * TH + wave * 2, tx * TW, lane, false);
+      return;
+    }
+  }
   const int ox = tx * TW + r;
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
@@ -247,8 +255,16 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
   for (int t = 0; t < d->ntaps; ++t)
     TDVC_CHECK(d->tap_dy[t] >= 0 && d->tap_dy[t] < d->kh && d->tap_dx[t] >= 0 && d->tap_dx[t] < d->kw,
                "tdvc_conv2d: tap %d out of the %dx%d window", t, d->kh, d->kw);
-  const int Ho = (d->x.H + 2 * d->pad - d->kh) / d->stride + 1;
-  const int Wo = (d->x.W + 2 * d->pad - d->kw) / d->stride + 1;
+  int Ho = (d->x.H + 2 * d->pad - d->kh) / d->stride + 1;
+  int Wo = (d->x.W + 2 * d->pad - d->kw) / d->stride + 1;
+  if (d->s2d) {
+    TDVC_CHECK(d->kh == 2 && d->kw == 2 && d->stride == 1 && d->pad == 1 && d->ntaps == 4 && d->ck == 32 && !d->square_input && !d->gdn,
+               "tdvc_conv2d: s2d expects the virtual 2x2 / stride 1 / pad 1 conv packed with ck=32");
+    TDVC_CHECK((d->x.H % 2) == 0 && (d->x.W % 2) == 0 && (d->x.C % 32) == 0 && d->cout >= 64,
+               "tdvc_conv2d: s2d needs even H, W, C %% 32 == 0 and cout >= 64 (got %dx%dx%d, cout %d)", d->x.H, d->x.W, d->x.C, d->cout);
+    Ho = d->x.H / 2;
+    Wo = d->x.W / 2;
+  }
   TDVC_CHECK(Ho > 0 && Wo > 0, "tdvc_conv2d: empty output");
   const int lds = lds_bytes(d->ck, d->kh, d->kw, d->stride);
   TDVC_CHECK(lds <= 64 * 1024, "tdvc_conv2d: LDS plan %d bytes too large (use tdvc_conv_plan)", lds);
@@ -291,7 +307,8 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
   p.res2 = d->res2.p ? to_dev(d->res2) : null_fmap();
   p.ntaps = d->ntaps; p.kh = d->kh; p.kw = d->kw; p.pad = d->pad;
   const int ck8 = d->ck / 8;
-  p.nchunks = (d->x.C + d->ck - 1) / d->ck;
+  p.s2d = d->s2d; p.Corig = d->x.C;
+  p.nchunks = d->s2d ? (4 * d->x.C) / d->ck : (d->x.C + d->ck - 1) / d->ck;
   p.steps = (d->ntaps * ck8 + 1) / 2;
   p.square = d->square_input; p.gdn = d->gdn; p.act = d->act; p.slope = d->slope;
   p.round16 = d->round_before_act; p.out_mode = d->out_mode;
@@ -301,15 +318,24 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
   p.tiles_x = tiles_x;
   const int tiles = cout_tiles(d->cout);
   const int mt = tiles == 1 ? 1 : 2;
+  if (mt == 2 && convk::conv_is_simple(p)) {
+    p.simple = 1;
+    p.slope = convk::conv_simple_slope(p);
+  }
+  if (d->s2d) {
+    TDVC_CHECK(conv_v3_eligible(d, Ho, Wo), "tdvc_conv2d: s2d conv not eligible for the stage-pipelined kernel");
+    return launch_conv_v3(p, tiles / 2, d->x.N, reinterpret_cast<hipStream_t>(stream));
+  }
   if (conv_v4_eligible(d, Ho, Wo)) return launch_conv_v4(p, tiles / 2, d->x.N, reinterpret_cast<hipStream_t>(stream));
   if (conv_v3_eligible(d, Ho, Wo)) return launch_conv_v3(p, tiles / 2, d->x.N, reinterpret_cast<hipStream_t>(stream));
   if (conv_v2_eligible(d, Ho, Wo)) return launch_conv_v2(p, 0, tiles / 2, d->x.N, reinterpret_cast<hipStream_t>(stream));
   dim3 grid(tiles_x * tiles_y, tiles / mt, d->x.N);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t lds_v1 = (p.simple && lds < 256 + 4 * 32 * 144) ? 256 + 4 * 32 * 144 : lds;
   switch (ck8) {
-    case 1: return launch_m<1>(p, mt, d->stride, grid, lds, st);
-    case 2: return launch_m<2>(p, mt, d->stride, grid, lds, st);
-    case 4: return launch_m<4>(p, mt, d->stride, grid, lds, st);
-    default: return launch_m<8>(p, mt, d->stride, grid, lds, st);
+    case 1: return launch_m<1>(p, mt, d->stride, grid, lds_v1, st);
+    case 2: return launch_m<2>(p, mt, d->stride, grid, lds_v1, st);
+    case 4: return launch_m<4>(p, mt, d->stride, grid, lds_v1, st);
+    default: return launch_m<8>(p, mt, d->stride, grid, lds_v1, st);
   }
 }

@@ -172,10 +172,8 @@ int launch_conv_v2(const ConvParams& p, int ntiles_unused, int cout_blocks, int 
   const int tiles_y = (p.Ho + TH2 - 1) / TH2;
   const int lds = v2_lds_bytes(p.kh, p.kw);
   // compact epilogue when the layer is the common case: fp16 NHWC out, bias, none/ReLU/LeakyReLU, fp16 residuals
-  const bool simple = p.out_mode == TDVC_OUT_NHWC && !p.y.f32 && !p.gdn && !p.round16 && p.bias &&
-                      (p.act == TDVC_ACT_NONE || p.act == TDVC_ACT_RELU || p.act == TDVC_ACT_LRELU) &&
-                      (!p.res.p || (!p.res.f32 && p.res.C >= p.y.C)) && (!p.res2.p || p.res2.C >= p.y.C);
-  if (simple) q.slope = p.act == TDVC_ACT_NONE ? 1.f : (p.act == TDVC_ACT_RELU ? 0.f : p.slope);
+  const bool simple = convk::conv_is_simple(p);
+  if (simple) q.slope = convk::conv_simple_slope(p);
   dim3 grid(q.tiles_x * tiles_y, cout_blocks, N);
   hipError_t err = hipSuccess;
   static bool attr_done = false;

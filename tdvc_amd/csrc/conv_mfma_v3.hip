@@ -81,12 +81,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v3_kernel(const ConvParams p
     const int tile = first + tile_i * stride;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     const int iy0 = ty * TH3 - p.pad, ix0 = tx * TW3 - p.pad;
-    const int cg = ch * CK3 + c8off;
+    int cg = ch * CK3 + c8off;
+    int sy = 1, oy_ = 0, ox_ = 0;                 // source pixel = sy * virtual + (oy_, ox_)
+    if (p.s2d) {
+      const int per = p.Corig / CK3;              // chunks per parity
+      const int qd = ch / per;
+      cg = (ch - qd * per) * CK3 + c8off;
+      sy = 2; oy_ = qd >> 1; ox_ = qd & 1;
+    }
 #pragma unroll
     for (int j = 0; j < TLOADS; ++j) {
-      const int iy = iy0 + it_rr[j], ix = ix0 + it_c[j];
+      const int iy = (iy0 + it_rr[j]) * sy + oy_, ix = (ix0 + it_c[j]) * sy + ox_;
       half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (it_dst[j] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && cg < p.Cin)
+      if (it_dst[j] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && (p.s2d || cg < p.Cin))
         v = *reinterpret_cast<const half8*>(xn + ((long)iy * p.W + ix) * p.x_sp + cg);
       treg[j] = v;
     }
@@ -193,7 +200,7 @@ bool conv_v3_eligible(const tdvc_conv_desc* d, int Ho, int Wo) {
   static const bool off = getenv("TDVC_CONV_NO_V3") != nullptr || getenv("TDVC_CONV_V1") != nullptr;
   if (off) return false;
   return d->ck == 32 && d->stride == 1 && d->ntaps >= 2 && d->ntaps <= WLOADS && d->kh <= 3 && d->kw <= 3 && d->cout >= 64 &&
-         d->x.C >= 32 && !d->square_input && (long)Ho * Wo >= 2048;
+         d->x.C >= 32 && !d->square_input && ((long)Ho * Wo >= 2048 || d->s2d);
 }
 
 int launch_conv_v3(const ConvParams& p, int cout_blocks, int N, hipStream_t st) {
@@ -204,10 +211,8 @@ int launch_conv_v3(const ConvParams& p, int cout_blocks, int N, hipStream_t st) 
   e.ntiles = q.tiles_x * tiles_y;
   e.tile_bytes = v3_tile_bytes(p.kh, p.kw);
   const int lds = v3_lds_bytes(p.kh, p.kw, p.ntaps);
-  const bool simple = p.out_mode == TDVC_OUT_NHWC && !p.y.f32 && !p.gdn && !p.round16 && p.bias &&
-                      (p.act == TDVC_ACT_NONE || p.act == TDVC_ACT_RELU || p.act == TDVC_ACT_LRELU) &&
-                      (!p.res.p || (!p.res.f32 && p.res.C >= p.y.C)) && (!p.res2.p || p.res2.C >= p.y.C);
-  if (simple) q.slope = p.act == TDVC_ACT_NONE ? 1.f : (p.act == TDVC_ACT_RELU ? 0.f : p.slope);
+  const bool simple = convk::conv_is_simple(p);
+  if (simple) q.slope = convk::conv_simple_slope(p);
   // persistent grid: two workgroups per CU over all (cout block, image) pairs
   int gx = 512 / (cout_blocks * N);
   if (gx < 1) gx = 1;

@@ -147,7 +147,13 @@ __global__ __launch_bounds__(NTHR, 1) void conv_mfma_v4_kernel(const ConvParams 
 #pragma unroll
     for (int j = 0; j < TLOADS4; ++j) {
       const u32x4 z = {0u, 0u, 0u, 0u};
-      if (it_dst[j] >= 0) *reinterpret_cast<u32x4*>(tbuf + it_dst[j]) = ((okmask[SET] >> j) & 1u) ? treg[SET][j] : z;
+      u32x4 val = ((okmask[SET] >> j) & 1u) ? treg[SET][j] : z;
+      if (p.square) {                       // GDN norm pool: stage x^2
+        half8 hv = __builtin_bit_cast(half8, val);
+        hv = hv * hv;
+        val = __builtin_bit_cast(u32x4, hv);
+      }
+      if (it_dst[j] >= 0) *reinterpret_cast<u32x4*>(tbuf + it_dst[j]) = val;
     }
     ST4(2);
     __syncthreads();
@@ -228,8 +234,8 @@ bool conv_v4_eligible(const tdvc_conv_desc* d, int Ho, int Wo) {
   static const bool off = getenv("TDVC_CONV_NO_V4") != nullptr || getenv("TDVC_CONV_V1") != nullptr;
   if (off) return false;
   const int nchunks = (d->x.C + CK4 - 1) / CK4;
-  return d->ck == 32 && d->stride == 1 && d->ntaps >= 2 && d->ntaps <= 9 && d->kh <= 3 && d->kw <= 3 && d->cout >= 64 &&
-         d->x.C >= 32 && !d->square_input && (long)Ho * Wo >= 8192 &&
+  return d->ck == 32 && d->stride == 1 && d->ntaps >= 1 && d->ntaps <= 9 && d->kh <= 3 && d->kw <= 3 && d->cout >= 64 &&
+         d->x.C >= 32 && !d->s2d && (long)Ho * Wo >= 8192 &&
          v4_lds_bytes(d->kh, d->kw, d->ntaps, nchunks) <= 150 * 1024;
 }
 
@@ -245,10 +251,8 @@ int launch_conv_v4(const ConvParams& p, int cout_blocks, int N, hipStream_t st) 
     e.stagger = stg;
   }
   const int lds = v4_lds_bytes(p.kh, p.kw, p.ntaps, p.nchunks);
-  const bool simple = p.out_mode == TDVC_OUT_NHWC && !p.y.f32 && !p.gdn && !p.round16 && p.bias &&
-                      (p.act == TDVC_ACT_NONE || p.act == TDVC_ACT_RELU || p.act == TDVC_ACT_LRELU) &&
-                      (!p.res.p || (!p.res.f32 && p.res.C >= p.y.C)) && (!p.res2.p || p.res2.C >= p.y.C);
-  if (simple) q.slope = p.act == TDVC_ACT_NONE ? 1.f : (p.act == TDVC_ACT_RELU ? 0.f : p.slope);
+  const bool simple = convk::conv_is_simple(p);
+  if (simple) q.slope = convk::conv_simple_slope(p);
   int gx = 256 / (cout_blocks * N);
   if (gx < 1) gx = 1;
   if (gx > e.ntiles) gx = e.ntiles;

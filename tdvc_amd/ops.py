@@ -112,14 +112,34 @@ class PackedConv:
     taps: list               # [(dy, dx)]
     shuffle: bool = False
     cin_real: int = 0        # un-padded input channels (algorithmic FLOP accounting)
+    s2d: bool = False        # stride-2 3x3 conv executed as a 2x2 conv over a space-to-depth view
+    flops_per_px: float = 0.0  # algorithmic FLOP per OUTPUT pixel of the ORIGINAL conv
 
 
 def _cout_pad(cout):
     return 32 if cout <= 32 else 64 * ((cout + 63) // 64)
 
 
+def _s2d_weights(w: torch.Tensor) -> torch.Tensor:
+    """(cout, C, 3, 3) stride-2 pad-1 kernel -> (cout, 4C, 2, 2) stride-1 kernel over the 2x2
+    space-to-depth view: virtual channel q*C + c = parity (py, px) = (q>>1, q&1); virtual tap (dy, dx)
+    covers original kernel row ky = 2*dy + py - 1 (zero weight when outside 0..2)."""
+    cout, C_, kh, kw = w.shape
+    assert (kh, kw) == (3, 3)
+    w2 = torch.zeros(cout, 4 * C_, 2, 2)
+    for py in range(2):
+        for px in range(2):
+            q = py * 2 + px
+            for dy in range(2):
+                for dx in range(2):
+                    ky, kx = 2 * dy + py - 1, 2 * dx + px - 1
+                    if 0 <= ky <= 2 and 0 <= kx <= 2:
+                        w2[:, q * C_:(q + 1) * C_, dy, dx] = w[:, :, ky, kx]
+    return w2
+
+
 def pack_conv(weight: torch.Tensor, bias: torch.Tensor | None, stride=1, pad=0, cin_pad: int | None = None,
-              taps=None, shuffle=False, cin_perm=None, device="cuda", ck=None) -> PackedConv:
+              taps=None, shuffle=False, cin_perm=None, device="cuda", ck=None, allow_s2d=True) -> PackedConv:
     """weight (cout, cin, kh, kw) fp32 (any device).  `taps`: list of (dy,dx) to keep (masked
     convs); `shuffle`: rows permuted for the PixelShuffle(2) store; `cin_perm`: index list applied
     to input channels (free re-ordering of concatenated inputs)."""
@@ -127,6 +147,12 @@ def pack_conv(weight: torch.Tensor, bias: torch.Tensor | None, stride=1, pad=0, 
     cout, cin_real, kh, kw = w.shape
     if cin_perm is not None:
         w = w[:, cin_perm]
+    if (allow_s2d and stride == 2 and (kh, kw) == (3, 3) and pad == 1 and cin_real % 32 == 0 and cout >= 64
+            and taps is None and not shuffle and ck is None):
+        pc = pack_conv(_s2d_weights(w), bias, stride=1, pad=1, device=device, ck=32, allow_s2d=False)
+        pc.s2d, pc.cin, pc.cin_real = True, cin_real, cin_real
+        pc.flops_per_px = 2.0 * cout * cin_real * 9
+        return pc
     b = torch.zeros(cout) if bias is None else bias.detach().float().cpu()
     if shuffle:
         assert cout % 4 == 0
@@ -139,7 +165,7 @@ def pack_conv(weight: torch.Tensor, bias: torch.Tensor | None, stride=1, pad=0, 
         taps = [(dy, dx) for dy in range(kh) for dx in range(kw)]
     lib = L.lib()
     if ck is None:
-        if stride == 1 and len(taps) >= 2 and cin >= 32 and cout >= 64:
+        if stride == 1 and cin >= 32 and cout >= 64:
             ck = 32          # the persistent pipelined kernel (conv_mfma_v2) streams 32-channel chunks
         else:
             ck = lib.tdvc_conv_plan(cin, kh, kw, stride)
@@ -162,8 +188,13 @@ def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, 
          res2: FM | None = None, gdn=GDN_NONE, aux: FM | None = None, square=False, out_dtype=torch.float16,
          round16=False, nchw_out: torch.Tensor | None = None) -> FM | torch.Tensor:
     assert x.C == pc.cin, f"conv: input has {x.C} channels, layer packed for {pc.cin}"
-    Ho = (x.H + 2 * pc.pad - pc.kh) // pc.stride + 1
-    Wo = (x.W + 2 * pc.pad - pc.kw) // pc.stride + 1
+    if pc.s2d:
+        if x.H % 2 or x.W % 2:
+            raise L.TdvcHipError("conv: the space-to-depth stride-2 path needs even H, W")
+        Ho, Wo = x.H // 2, x.W // 2
+    else:
+        Ho = (x.H + 2 * pc.pad - pc.kh) // pc.stride + 1
+        Wo = (x.W + 2 * pc.pad - pc.kw) // pc.stride + 1
     d = L.ConvDesc()
     d.x = x.desc()
     d.w = pc.w.data_ptr()
@@ -177,6 +208,7 @@ def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, 
     d.act, d.slope, d.round_before_act = act, slope, int(round16)
     d.res = res.desc() if res is not None else _NULL_FM
     d.res2 = res2.desc() if res2 is not None else _NULL_FM
+    d.s2d = int(pc.s2d)
     if nchw_out is not None:
         assert nchw_out.shape == (x.N, pc.cout, Ho, Wo) and nchw_out.dtype == torch.float32 and nchw_out.is_contiguous()
         d.out_mode = OUT_NCHW_F32
@@ -199,13 +231,14 @@ def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, 
         e0.record()
         L.check(L.lib().tdvc_conv2d(C.byref(d), _stream()), "conv2d")
         e1.record()
-        v2 = pc.ck == 32 and pc.stride == 1 and len(pc.taps) >= 2 and pc.cout >= 64 and Ho * Wo >= 2048
+        v2 = pc.ck == 32 and pc.stride == 1 and len(pc.taps) >= 2 and pc.cout >= 64 and (Ho * Wo >= 2048 or pc.s2d)
         v3 = v2 and len(pc.taps) <= 9 and pc.kh <= 3 and pc.kw <= 3
-        v4 = v3 and Ho * Wo >= 8192 and 256 + 18 * 34 * 80 + ((x.C + 31) // 32) * len(pc.taps) * 4096 <= 150 * 1024
-        PROFILE.append(dict(kernel="conv_mfma_v4" if v4 else "conv_mfma_v3" if v3 else "conv_mfma_v2" if v2 else f"conv_mfma<{pc.ck // 8},{1 if pc.cout <= 32 else 2},{pc.stride}>",
+        v41 = pc.ck == 32 and pc.stride == 1 and len(pc.taps) == 1 and pc.cout >= 64 and Ho * Wo >= 8192
+        v4 = (v3 or v41) and not pc.s2d and Ho * Wo >= 8192 and 256 + 18 * 34 * 80 + ((x.C + 31) // 32) * len(pc.taps) * 4096 <= 150 * 1024
+        PROFILE.append(dict(kernel="conv_mfma_v4" if v4 else "conv_mfma_v3(s2d)" if (v3 and pc.s2d) else "conv_mfma_v3" if v3 else "conv_mfma_v2" if v2 else f"conv_mfma<{pc.ck // 8},{1 if pc.cout <= 32 else 2},{pc.stride}>",
                             e0=e0, e1=e1,
                             flops=2.0 * x.N * Ho * Wo * pc.cout * x.C * len(pc.taps),
-                            flops_real=2.0 * x.N * Ho * Wo * pc.cout * pc.cin_real * len(pc.taps),
+                            flops_real=(x.N * Ho * Wo * pc.flops_per_px) if pc.s2d else 2.0 * x.N * Ho * Wo * pc.cout * pc.cin_real * len(pc.taps),
                             bytes=2.0 * x.N * (x.H * x.W * x.C + Ho * Wo * pc.cout * (4 if pc.shuffle else 1) / (4 if pc.shuffle else 1))))
         return ret
     L.check(L.lib().tdvc_conv2d(C.byref(d), _stream()), "conv2d")

@@ -231,3 +231,64 @@ def test_conv_v2_masked_shuffle_slices(report):
     ops.conv(src.as_slices(0, T, 64), ops.pack_conv(w, b, stride=1, pad=1), out=dst.as_slices(0, T, 64), res=rb.as_slices(0, T, 64))
     ref = torch.cat([F.conv2d(x[:, t * 64:(t + 1) * 64], w, b, padding=1) for t in range(T)], 1) + rr
     assert_close(fm_to_cpu(dst), ref, RT, AT, "v2 frame slices + residual", report)
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_conv_gdn_large(inverse, report):
+    """GDN / iGDN at a size that takes the weight-stationary kernel (1x1, squared-input prologue,
+    aux * (r)sqrt epilogue through LDS) with a residual"""
+    ops = _ops()
+    C, H, W = 128, 96, 112
+    x = rnd16(randn(1, C, H, W, seed=61))
+    gamma = rnd16(torch.rand(C, C, generator=torch.Generator().manual_seed(62)) * 0.02 + 0.1 * torch.eye(C))
+    beta = torch.rand(C, generator=torch.Generator().manual_seed(63)) + 0.5
+    r = rnd16(randn(1, C, H, W, seed=64))
+    norm = F.conv2d(rnd16(x * x), gamma.view(C, C, 1, 1), beta)
+    ref = x * (torch.sqrt(norm) if inverse else torch.rsqrt(norm)) + r
+    xf = to_fm(x, ops)
+    pc = ops.pack_conv(gamma.view(C, C, 1, 1), beta, stride=1, pad=0)
+    assert pc.ck == 32
+    y = ops.conv(xf, pc, square=True, gdn=ops.GDN_INV if inverse else ops.GDN_FWD, aux=xf, res=to_fm(r, ops))
+    assert_close(fm_to_cpu(y), ref, 4e-3, 4e-3, f"GDN large inverse={inverse}", report)
+
+
+def test_conv_1x1_large_and_shuffle_large(report):
+    ops = _ops()
+    # 1x1 256 -> 64 (multi-frame fusion) on the weight-stationary kernel
+    x = rnd16(randn(1, 256, 96, 128, seed=65))
+    w = rnd16(randn(64, 256, 1, 1, seed=66) * 0.06)
+    b = randn(64, seed=67) * 0.1
+    y = ops.conv(to_fm(x, ops), ops.pack_conv(w, b, stride=1, pad=0), act=ops.ACT_LRELU, slope=0.1)
+    assert_close(fm_to_cpu(y), F.leaky_relu(F.conv2d(x, w, b), 0.1), RT, AT, "1x1 256->64 large", report)
+    # sub-pixel conv 64-ch in, 128 -> 4*64 packed rows, on the weight-stationary kernel with residual
+    x = rnd16(randn(1, 64, 96, 128, seed=68))
+    w = rnd16(randn(256, 64, 3, 3, seed=69) * 0.04)
+    b = randn(256, seed=70) * 0.1
+    r = rnd16(randn(1, 64, 192, 256, seed=71))
+    ref = F.pixel_shuffle(F.conv2d(x, w, b, padding=1), 2) + r
+    y = ops.conv(to_fm(x, ops), ops.pack_conv(w, b, stride=1, pad=1, shuffle=True), res=to_fm(r, ops))
+    assert_close(fm_to_cpu(y), ref, RT, AT, "subpel 64->64 large (v4)", report)
+    # 128 -> 512 shuffle at a v3 size, LeakyReLU(0.01)
+    x = rnd16(randn(1, 128, 68, 120, seed=72))
+    w = rnd16(randn(512, 128, 3, 3, seed=73) * 0.03)
+    b = randn(512, seed=74) * 0.1
+    ref = F.leaky_relu(F.pixel_shuffle(F.conv2d(x, w, b, padding=1), 2), 0.01)
+    y = ops.conv(to_fm(x, ops), ops.pack_conv(w, b, stride=1, pad=1, shuffle=True), act=ops.ACT_LRELU, slope=0.01)
+    assert_close(fm_to_cpu(y), ref, RT, AT, "subpel 128->128 (v3)", report)
+
+
+@pytest.mark.parametrize("H,W", [(64, 96), (34, 60), (270, 480)])
+def test_conv_stride2_s2d(H, W, report):
+    """3x3 stride-2 conv executed as a 2x2 conv over the space-to-depth view"""
+    ops = _ops()
+    x = rnd16(randn(2, 64, H, W, seed=75))
+    w = rnd16(randn(128, 64, 3, 3, seed=76) * 0.04)
+    b = randn(128, seed=77) * 0.1
+    pc = ops.pack_conv(w, b, stride=2, pad=1)
+    assert pc.s2d
+    y = ops.conv(to_fm(x, ops), pc, act=ops.ACT_LRELU, slope=0.01)
+    assert_close(fm_to_cpu(y), F.leaky_relu(F.conv2d(x, w, b, stride=2, padding=1), 0.01), RT, AT, f"s2d {H}x{W}", report)
+    # fp32 output (the last analysis conv) takes the generic epilogue
+    y = ops.conv(to_fm(x, ops), pc, out_dtype=torch.float32)
+    assert y.f32
+    assert_close(fm_to_cpu(y), F.conv2d(x, w, b, stride=2, padding=1), 1e-4, 1e-4, f"s2d fp32 out {H}x{W}", report)

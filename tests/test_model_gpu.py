@@ -83,8 +83,10 @@ def test_forward_vs_oracle(models, H, W, report):
         # rate; the untrained synthetic weights run at several bpp, so the gate is 0.001 + 0.5 %.
         assert abs(float(bro) - float(brg)) <= 1e-3 + 5e-3 * float(bro), "bpp_res delta"
         assert abs(float(bmo) - float(bmg)) <= 1e-3 + 5e-3 * float(bmo), "bpp_mv delta"
-        for k in ("f_cur", "f_ref", "estmv", "pred1", "pred", "resid"):
+        for k in ("f_cur", "f_ref", "estmv"):                 # upstream of any quantiser: pure fp16-vs-fp32 drift
             assert st[k] < 1e-2, (k, st[k])
+        for k in ("pred1", "pred", "resid"):                  # downstream of round(): includes flipped symbols
+            assert st[k] < 3e-2, (k, st[k])
         # quantiser-symbol flips vs the fp32 oracle (diagnostic): fp16 activations upstream of round();
         # the residual coder's input already carries the motion coder's flips, hence the wider bound
         assert st["mv.y_hat_flips"] < 5e-3 and st["res.y_hat_flips"] < 2e-2
