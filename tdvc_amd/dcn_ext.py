@@ -31,3 +31,34 @@ def dcn_v2_backward(input, weight, bias, offset, mask, grad_output, kh, kw, sh, 
             cols.data_ptr(), B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, deformable_group, _stream()),
             "dcn_v2_backward")
     return [gi, go, gm, gw, gb]
+
+
+class _DCNv2(torch.autograd.Function):
+    """autograd twin of the reference's `_DCNv2` (main/utils/dcnv2/dcn_v2_amp.py:23-119): fp32 compute,
+    optional fp16 rounding of the output / gradients (`use_amp`, which the reference leaves True)."""
+
+    @staticmethod
+    def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, use_amp=True):
+        from .ops import dcn_v2_forward
+        if use_amp:
+            input, offset, mask, weight, bias = (t.float() for t in (input, offset, mask, weight, bias))
+        kh, kw = weight.shape[2:4]
+        ctx.cfg = (kh, kw, stride, stride, padding, padding, dilation, dilation, deformable_groups)
+        ctx.use_amp = use_amp
+        out = dcn_v2_forward(input, weight, bias, offset, mask, *ctx.cfg)
+        ctx.save_for_backward(input, offset, mask, weight, bias)
+        return out.half() if use_amp else out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        input, offset, mask, weight, bias = ctx.saved_tensors
+        go = grad_output.float().contiguous() if ctx.use_amp else grad_output.contiguous()
+        gi, goff, gm, gw, gb = dcn_v2_backward(input, weight, bias, offset, mask, go, *ctx.cfg)
+        if ctx.use_amp:
+            gi, goff, gm, gw, gb = (t.half() for t in (gi, goff, gm, gw, gb))
+        return gi, goff, gm, gw, gb, None, None, None, None, None
+
+
+def dcn_v2_conv(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, use_amp=True):
+    return _DCNv2.apply(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, use_amp)

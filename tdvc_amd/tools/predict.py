@@ -1,0 +1,95 @@
+#!/usr/bin/env python
+"""Counterpart of the reference's tools/predict.py GOP loop on the MI355X path.
+
+The reference script needs CUDA at import, cv2/natsort datasets under /dataset/... and a
+checkpoint that does not ship; this driver keeps its behaviour — yaml keys
+`model, pretrain, val_dataset, class, enable_amp`, the reference-list rule (:55-62), pad/crop to 64
+(:51-53,69-70), PSNR / bpp averaging over all frames (:87-108) — on synthetic GOPs (or a checkpoint
+given by --pretrain), one process per GPU with GOPs sharded round-robin across ranks.
+
+  python -m tdvc_amd.tools.predict --gops 2 --height 1080 --width 1920
+  python -m torch.distributed.run --nproc-per-node 8 -m tdvc_amd.tools.predict --gops 16
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import time
+
+import torch
+import yaml
+
+from ..codec_utils import crop, pad, psnr
+from ..model import VideoCompressor
+from ..parallel import gather_frame_stats, shard_gops
+from ..synth import fill_parameters, make_gop, ref_list
+
+
+def code_gop(net, frames: torch.Tensor, enable_amp: bool = True):
+    """frames: (T,3,h,w) on the GPU, frame 0 = I-frame reconstruction. Returns per-P-frame stats."""
+    h, w = frames.shape[-2:]
+    refs = [pad(frames[0:1], 64)]
+    stats = []
+    for t in range(1, frames.shape[0]):
+        x = pad(frames[t:t + 1], 64)
+        recon, bpp_res, bpp_mv = net(x, ref_list(refs), enable_amp)
+        refs.append(recon)                                   # padded reconstruction re-enters the list (:68)
+        rc, xc = crop(recon, (h, w)), crop(x, (h, w))
+        stats.append({"frame": t, "psnr": psnr(rc, xc), "bpp": float(bpp_res + bpp_mv),
+                      "bpp_mv": float(bpp_mv), "bpp_res": float(bpp_res)})
+    return stats
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfg", default=None, help="yaml with the reference's predict keys")
+    ap.add_argument("--pretrain", default=None, help="state-dict checkpoint (reference key names); default: synthetic filler")
+    ap.add_argument("--gops", type=int, default=2)
+    ap.add_argument("--gop-size", type=int, default=7)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    opt = {"model": "pnet", "pretrain": a.pretrain, "val_dataset": "synthetic", "class": "-", "enable_amp": True}
+    if a.cfg:
+        opt.update(yaml.safe_load(open(a.cfg)))
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    torch.cuda.set_device(dev)
+    net = VideoCompressor()
+    if opt["pretrain"] and os.path.exists(str(opt["pretrain"])):
+        net.load_state_dict(torch.load(opt["pretrain"], map_location="cpu"), strict=True)
+    else:
+        fill_parameters(net)
+    net = net.to(dev).eval()
+    t0 = time.time()
+    stats = []
+    with torch.no_grad():
+        for g in shard_gops(a.gops, world, rank):
+            frames = make_gop(2000 + g, a.gop_size, a.height, a.width).to(dev)
+            for s in code_gop(net, frames, bool(opt["enable_amp"])):
+                s["gop"] = g
+                stats.append(s)
+    torch.cuda.synchronize()
+    allstats = gather_frame_stats(stats)
+    if rank == 0:
+        n = max(1, len(allstats))
+        res = {"frames": len(allstats), "bpp": sum(s["bpp"] for s in allstats) / n,
+               "psnr": sum(s["psnr"] for s in allstats) / n, "seconds": time.time() - t0, "cfg": opt}
+        print(json.dumps(res))
+        if a.out:
+            with open(a.out, "w") as f:
+                f.write("bpp : %.6f\n\npsnr : %.6f\n" % (res["bpp"], res["psnr"]))
+                f.write("cfg :\n" + json.dumps(opt, indent=4) + "\ncost_time :\n" + str(res["seconds"]) + "\n")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

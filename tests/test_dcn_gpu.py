@@ -94,3 +94,48 @@ def test_fused_dcn_vs_oracle(H, W, report):
     dst = ops.FM.empty(2, H, W, 64)
     m.run(to_fm(x, ops), to_fm(y, ops), dst, act=ops.ACT_LRELU, slope=0.1)
     assert_close(fm_to_cpu(dst), want, 4e-3, 4e-3, f"fused DCN {H}x{W}", report)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, C=2, Cout=2, H=4, W=4, k=3, s=1, p=1, d=1, G=1, osc=2.0),       # testcpu.py gradcheck geometry
+    dict(B=2, C=64, Cout=64, H=12, W=20, k=3, s=1, p=1, d=1, G=8, osc=2.5),   # hot-path geometry
+    dict(B=1, C=16, Cout=24, H=11, W=13, k=3, s=2, p=1, d=1, G=4, osc=1.5),
+    dict(B=1, C=8, Cout=8, H=9, W=9, k=3, s=1, p=2, d=2, G=2, osc=4.0),
+])
+def test_ext_backward_vs_oracle(cfg, report):
+    """`_ext.dcn_v2_backward` vs the C restatement of the reference's CPU backward kernels"""
+    import _ext
+    from oracle import dcn_c
+    B, C, Cout, H, W, k, s, p, d, G = (cfg[x] for x in ("B", "C", "Cout", "H", "W", "k", "s", "p", "d", "G"))
+    Ho = (H + 2 * p - (d * (k - 1) + 1)) // s + 1
+    Wo = (W + 2 * p - (d * (k - 1) + 1)) // s + 1
+    x = randn(B, C, H, W, seed=12)
+    w = randn(Cout, C, k, k, seed=13, scale=0.2)
+    b = randn(Cout, seed=14)
+    off = randn(B, 2 * G * k * k, Ho, Wo, seed=15, scale=cfg["osc"])
+    m = torch.sigmoid(randn(B, G * k * k, Ho, Wo, seed=16))
+    gy = randn(B, Cout, Ho, Wo, seed=17)
+    want = dcn_c.backward(x, w, b, off, m, gy, k, k, s, s, p, p, d, d, G)
+    got = _ext.dcn_v2_backward(x.cuda(), w.cuda(), b.cuda(), off.cuda(), m.cuda(), gy.cuda(), k, k, s, s, p, p, d, d, G)
+    assert len(got) == 5
+    for name, a, r in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), got, want):
+        scale = float(r.abs().max()) + 1e-6
+        assert_close(a.cpu(), r, 1e-4, 2e-5 * scale + 1e-6, f"_ext.dcn_v2_backward {name} C={C} {H}x{W}", report)
+
+
+def test_ext_autograd_function(report):
+    """the product-side autograd wrapper (twin of `_DCNv2`, dcn_v2_amp.py:23-119) backpropagates"""
+    from tdvc_amd.dcn_ext import dcn_v2_conv
+    from oracle import dcn_c
+    x = randn(1, 8, 9, 9, seed=18).cuda().requires_grad_()
+    w = randn(8, 8, 3, 3, seed=19, scale=0.2).cuda().requires_grad_()
+    b = randn(8, seed=20).cuda().requires_grad_()
+    off = randn(1, 2 * 2 * 9, 9, 9, seed=21, scale=1.5).cuda().requires_grad_()
+    m = torch.sigmoid(randn(1, 2 * 9, 9, 9, seed=22)).cuda().requires_grad_()
+    y = dcn_v2_conv(x, off, m, w, b, 1, 1, 1, 2, use_amp=False)
+    gy = randn(*y.shape, seed=23).cuda()
+    y.backward(gy)
+    want = dcn_c.backward(x.detach().cpu(), w.detach().cpu(), b.detach().cpu(), off.detach().cpu(), m.detach().cpu(), gy.cpu(),
+                          3, 3, 1, 1, 1, 1, 1, 1, 2)
+    for t, r in zip((x, off, m, w, b), want):
+        assert_close(t.grad.cpu(), r, 1e-4, 1e-4, "autograd grad", report)

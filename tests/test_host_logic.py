@@ -78,3 +78,15 @@ def test_pack_conv_host_options():
     mc = MaskedConv2d(8, 16, kernel_size=5, padding=2)
     taps = mc.live_taps()
     assert len(taps) == 12 and all(mc.mask[0, 0, dy, dx] == 1 for dy, dx in taps) and int(mc.mask[0, 0].sum()) == 12
+
+
+def test_pad_crop_match_oracle():
+    from oracle.tdvc_ref.blocks import crop_to, pad_to
+    from tdvc_amd.codec_utils import crop, pad
+    x = torch.randn(2, 3, 1080, 1920)
+    p = pad(x, 64)
+    assert p.shape[-2:] == (1088, 1920) and torch.equal(p, pad_to(x, 64))
+    assert torch.equal(p[..., :4, :], torch.zeros(2, 3, 4, 1920)) and torch.equal(p[..., -4:, :], torch.zeros(2, 3, 4, 1920))
+    assert torch.equal(crop(p, (1080, 1920)), x) and torch.equal(crop(p, (1080, 1920)), crop_to(p, (1080, 1920)))
+    y = torch.randn(1, 3, 59, 67)
+    assert torch.equal(pad(y, 64), pad_to(y, 64)) and torch.equal(crop(pad(y, 64), (59, 67)), y)
