@@ -220,6 +220,43 @@ int tdvc_rans_decode(const uint8_t* data, int64_t nbytes, const int32_t* indexes
                      const int32_t* cdfs, int32_t cdf_stride, const int32_t* cdf_sizes,
                      const int32_t* offsets, int32_t* symbols_out);
 
+/* Stateful decoder (compressai RansDecoder.set_stream / decode_stream): create copies the stream;
+ * decode continues where the previous call stopped. */
+void* tdvc_rans_decoder_create(const uint8_t* data, int64_t nbytes);
+int tdvc_rans_decoder_decode(void* handle, const int32_t* indexes, int64_t n, const int32_t* cdfs,
+                             int32_t cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets,
+                             int32_t* symbols_out);
+void tdvc_rans_decoder_destroy(void* handle);
+
+/* compressai `_CXX.pmf_to_quantized_cdf` (used by EntropyModel._pmf_to_cdf inside update(),
+ * main/model/pnet.py:47,71): pmf[n] -> quantised cdf[n+1] at `precision` bits, every bin >= 1. Host code. */
+int tdvc_pmf_to_quantized_cdf(const float* pmf, int n, int precision, int32_t* cdf_out);
+
+/* ---------------------------------------------------------------- autoregressive context model (compress)
+ * `_compress_ar` / `_decompress_ar` of compressai's JointAutoregressiveHierarchicalPriors, called from
+ * main/model/pnet.py:48,72.  Position (h, w) depends on rows h-2..h within +-2 columns, so positions
+ * with equal w + 3h are independent: the encoder walks W + 3(H-1) anti-diagonal steps, each step a
+ * batch of <= H positions whose 12-tap neighbourhoods are gathered into a dense matrix
+ * (tdvc_ar_gather), pushed through the context conv and entropy_parameters as 1x1 MFMA convs, then
+ * quantised and written back (tdvc_ar_quantize).
+ * pos: int32 [npos][2] = (h, w) on the device.  y_hat: fp16 fmap (H, W, M), zero-initialised.
+ * params: fp16 fmap (H, W, 2M) (h_s output).  x1: fp16 fmap (1, 1, npos, 12*M) neighbourhoods in tap-major
+ * order; pc: fp16 fmap (1, 1, npos, 4M): channels [0, 2M) receive params of the positions. */
+int tdvc_ar_gather(const tdvc_fmap* y_hat, const tdvc_fmap* params, const int32_t* pos, int npos,
+                   const tdvc_fmap* x1, const tdvc_fmap* pc, void* stream);
+/* gp: fp32 fmap (1, 1, npos, 2M) [scales | means].  Encoder (symbols_in == NULL): q = round(y - mean);
+ * decoder: q = symbols_in[h][w][c].  Writes y_hat[h][w][c] = q + mean, symbols[h][w][c] = q (int32,
+ * [H][W][M]) and indexes[h][w][c] = #{table entries < max(scale, 0.11)} clipped to ntable-1
+ * (GaussianConditional.build_indexes).  scale_table: ntable floats. */
+int tdvc_ar_quantize(const tdvc_fmap* y, const tdvc_fmap* gp, const int32_t* pos, int npos,
+                     const float* scale_table, int ntable, const int32_t* symbols_in,
+                     const tdvc_fmap* y_hat, int32_t* symbols, int32_t* indexes, void* stream);
+/* indexes only (decoder: needed before the symbols can be read from the stream). */
+int tdvc_ar_indexes(const tdvc_fmap* gp, const int32_t* pos, int npos, const float* scale_table, int ntable,
+                    int M, int W, int32_t* indexes, void* stream);
+/* q[n][h][w][c] = round(z - median[c]) as int32 in the fmap's own order (factorised-prior symbols). */
+int tdvc_round_symbols(const tdvc_fmap* z, const float* median, int32_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,14 @@ SIGNATURES = {
     "tdvc_quantize": (_i, [_FM, _FM, _FM, _P]),
     "tdvc_rans_encode": (_i64, [_P, _P, _i64, _P, C.c_int32, _P, _P, _P, _i64]),
     "tdvc_rans_decode": (_i, [_P, _i64, _P, _i64, _P, C.c_int32, _P, _P, _P]),
+    "tdvc_rans_decoder_create": (_P, [_P, _i64]),
+    "tdvc_rans_decoder_decode": (_i, [_P, _P, _i64, _P, C.c_int32, _P, _P, _P]),
+    "tdvc_rans_decoder_destroy": (None, [_P]),
+    "tdvc_pmf_to_quantized_cdf": (_i, [_P, _i, _i, _P]),
+    "tdvc_ar_gather": (_i, [_FM, _FM, _P, _i, _FM, _FM, _P]),
+    "tdvc_ar_quantize": (_i, [_FM, _FM, _P, _i, _P, _i, _P, _FM, _P, _P, _P]),
+    "tdvc_ar_indexes": (_i, [_FM, _P, _i, _P, _i, _i, _i, _P, _P]),
+    "tdvc_round_symbols": (_i, [_FM, _P, _P, _P]),
 }
 
 _lib = None

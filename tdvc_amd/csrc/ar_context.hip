@@ -1,0 +1,121 @@
+// Autoregressive context-model support kernels (compress / decompress): gather the causal 5x5
+// neighbourhoods of a batch of independent positions, quantise them and scatter them back.
+// The dense math in between (context conv as a 12*M -> 2M 1x1 conv, entropy_parameters) runs on the
+// MFMA conv kernel.  All integer / index outputs are exact; nothing here uses atomics.
+#include "common.h"
+
+namespace {
+
+// the 12 causal taps of the type-A 5x5 mask in raster order: (dy, dx) relative to the centre
+__constant__ int8_t kTapDy[12] = {-2, -2, -2, -2, -2, -1, -1, -1, -1, -1, 0, 0};
+__constant__ int8_t kTapDx[12] = {-2, -1, 0, 1, 2, -2, -1, 0, 1, 2, -2, -1};
+
+__global__ void ar_gather_kernel(FMap yh, FMap pr, const int32_t* pos, int npos, FMap x1, FMap pc) {
+  const int M8 = yh.C / 8;                        // 16-byte chunks per position
+  const int per = 12 * M8 + pr.C / 8;             // chunks to move per position
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)npos * per) return;
+  const int k = (int)(i / per), u = (int)(i % per);
+  const int h = pos[2 * k], w = pos[2 * k + 1];
+  if (u < 12 * M8) {
+    const int t = u / M8, c8 = u % M8;
+    const int yy = h + kTapDy[t], xx = w + kTapDx[t];
+    half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (yy >= 0 && xx >= 0 && xx < yh.W)
+      v = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(yh.p) + ((long)yy * yh.W + xx) * yh.sp + c8 * 8);
+    *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(x1.p) + (long)k * x1.sp + (t * M8 + c8) * 8) = v;
+  } else {
+    const int c8 = u - 12 * M8;
+    const half8 v = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(pr.p) + ((long)h * pr.W + w) * pr.sp + c8 * 8);
+    *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(pc.p) + (long)k * pc.sp + c8 * 8) = v;
+  }
+}
+
+__device__ __forceinline__ int scale_index(float s, const float* table, int n) {
+  s = fmaxf(s, 0.11f);
+  int idx = n - 1;
+  for (int j = 0; j < n - 1; ++j) idx -= (s <= table[j]) ? 1 : 0;
+  return idx;
+}
+
+__global__ void ar_quantize_kernel(FMap y, FMap gp, const int32_t* pos, int npos, const float* table, int ntable,
+                                   const int32_t* sym_in, FMap yh, int32_t* sym, int32_t* idx) {
+  const int M = y.C;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)npos * M) return;
+  const int k = (int)(i / M), c = (int)(i % M);
+  const int h = pos[2 * k], w = pos[2 * k + 1];
+  const float* g = reinterpret_cast<const float*>(gp.p) + (long)k * gp.sp;
+  const float scale = g[c], mean = g[M + c];
+  const long o = ((long)h * y.W + w) * M + c;
+  int q;
+  if (sym_in) q = sym_in[o];
+  else q = (int)rintf(reinterpret_cast<const float*>(y.p)[((long)h * y.W + w) * y.sp + c] - mean);
+  reinterpret_cast<half_t*>(yh.p)[((long)h * yh.W + w) * yh.sp + c] = (half_t)((float)q + mean);
+  sym[o] = q;
+  idx[o] = scale_index(scale, table, ntable);
+}
+
+__global__ void ar_indexes_kernel(FMap gp, const int32_t* pos, int npos, const float* table, int ntable, int M, int W, int32_t* idx) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)npos * M) return;
+  const int k = (int)(i / M), c = (int)(i % M);
+  const int h = pos[2 * k], w = pos[2 * k + 1];
+  const float* g = reinterpret_cast<const float*>(gp.p) + (long)k * gp.sp;
+  idx[((long)h * W + w) * M + c] = scale_index(g[c], table, ntable);
+}
+
+__global__ void round_symbols_kernel(FMap z, const float* median, int32_t* out) {
+  const long npix = (long)z.H * z.W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * z.C * z.N) return;
+  const int c = (int)(i % z.C);
+  const long t = i / z.C;
+  const long pix = t % npix;
+  const int n = (int)(t / npix);
+  out[i] = (int)rintf(reinterpret_cast<const float*>(z.p)[(long)n * z.sn + pix * z.sp + c] - median[c]);
+}
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+inline dim3 g1(long n) { return dim3((unsigned)((n + 255) / 256)); }
+
+}  // namespace
+
+extern "C" int tdvc_ar_gather(const tdvc_fmap* y_hat, const tdvc_fmap* params, const int32_t* pos, int npos,
+                              const tdvc_fmap* x1, const tdvc_fmap* pc, void* stream) {
+  TDVC_CHECK(y_hat && params && pos && x1 && pc && npos >= 1, "tdvc_ar_gather: null / empty");
+  TDVC_CHECK(fmap_ok16(*y_hat) && fmap_ok16(*params) && fmap_ok16(*x1) && fmap_ok16(*pc), "tdvc_ar_gather: fp16 fmaps expected");
+  TDVC_CHECK(y_hat->N == 1 && params->N == 1 && params->H == y_hat->H && params->W == y_hat->W, "tdvc_ar_gather: one image at a time, params geometry must match y_hat");
+  TDVC_CHECK(x1->C == 12 * y_hat->C && x1->W >= npos && x1->H == 1 && pc->C >= params->C && pc->W >= npos && pc->H == 1,
+             "tdvc_ar_gather: x1 must be (1,1,>=npos,12*M), pc (1,1,>=npos,>=2M)");
+  const long total = (long)npos * (12 * y_hat->C / 8 + params->C / 8);
+  hipLaunchKernelGGL(ar_gather_kernel, g1(total), dim3(256), 0, ST(stream), to_dev(*y_hat), to_dev(*params), pos, npos, to_dev(*x1), to_dev(*pc));
+  return tdvc_launch_status("tdvc_ar_gather");
+}
+
+extern "C" int tdvc_ar_quantize(const tdvc_fmap* y, const tdvc_fmap* gp, const int32_t* pos, int npos,
+                                const float* scale_table, int ntable, const int32_t* symbols_in,
+                                const tdvc_fmap* y_hat, int32_t* symbols, int32_t* indexes, void* stream) {
+  TDVC_CHECK(gp && pos && scale_table && y_hat && symbols && indexes && npos >= 1 && ntable >= 2, "tdvc_ar_quantize: null / empty");
+  TDVC_CHECK(symbols_in || (y && fmap_ok32(*y)), "tdvc_ar_quantize: need y (encoder) or symbols_in (decoder)");
+  TDVC_CHECK(fmap_ok32(*gp) && fmap_ok16(*y_hat) && y_hat->N == 1 && gp->C >= 2 * y_hat->C && gp->W >= npos, "tdvc_ar_quantize: bad gp / y_hat");
+  FMap yd = y ? to_dev(*y) : to_dev(*y_hat);
+  yd.C = y_hat->C; yd.W = y_hat->W; yd.H = y_hat->H;
+  hipLaunchKernelGGL(ar_quantize_kernel, g1((long)npos * y_hat->C), dim3(256), 0, ST(stream), yd, to_dev(*gp), pos, npos, scale_table, ntable,
+                     symbols_in, to_dev(*y_hat), symbols, indexes);
+  return tdvc_launch_status("tdvc_ar_quantize");
+}
+
+extern "C" int tdvc_ar_indexes(const tdvc_fmap* gp, const int32_t* pos, int npos, const float* scale_table, int ntable,
+                               int M, int W, int32_t* indexes, void* stream) {
+  TDVC_CHECK(gp && pos && scale_table && indexes && npos >= 1 && ntable >= 2 && M >= 1 && W >= 1 && fmap_ok32(*gp) && gp->C >= 2 * M,
+             "tdvc_ar_indexes: bad arguments");
+  hipLaunchKernelGGL(ar_indexes_kernel, g1((long)npos * M), dim3(256), 0, ST(stream), to_dev(*gp), pos, npos, scale_table, ntable, M, W, indexes);
+  return tdvc_launch_status("tdvc_ar_indexes");
+}
+
+extern "C" int tdvc_round_symbols(const tdvc_fmap* z, const float* median, int32_t* out, void* stream) {
+  TDVC_CHECK(z && median && out && fmap_ok32(*z), "tdvc_round_symbols: bad arguments");
+  hipLaunchKernelGGL(round_symbols_kernel, g1((long)z->N * z->H * z->W * z->C), dim3(256), 0, ST(stream), to_dev(*z), median, out);
+  return tdvc_launch_status("tdvc_round_symbols");
+}

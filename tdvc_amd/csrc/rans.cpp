@@ -4,6 +4,7 @@
 // which `Cheng2020Anchor.compress` drives from main/model/pnet.py:46-49,70-73.  It is host code
 // in the reference as well; the GPU produces the symbols and CDF indexes, this packs them.
 #include <stdint.h>
+#include <string.h>
 #include <vector>
 
 #include "../../include/tdvc_hip.h"
@@ -104,6 +105,9 @@ struct Dec {
 };
 }  // namespace
 
+static int dec_run(Dec& dc, const int32_t* indexes, int64_t n, const int32_t* cdfs, int32_t cdf_stride,
+                   const int32_t* cdf_sizes, const int32_t* offsets, int32_t* symbols_out);
+
 extern "C" int tdvc_rans_decode(const uint8_t* data, int64_t nbytes, const int32_t* indexes, int64_t n,
                                 const int32_t* cdfs, int32_t cdf_stride, const int32_t* cdf_sizes,
                                 const int32_t* offsets, int32_t* symbols_out) {
@@ -114,6 +118,41 @@ extern "C" int tdvc_rans_decode(const uint8_t* data, int64_t nbytes, const int32
   Dec dc{data, nbytes / 4, 0, 0, false};
   const uint64_t lo = dc.word(), hi = dc.word();
   dc.x = lo | (hi << 32);
+  return dec_run(dc, indexes, n, cdfs, cdf_stride, cdf_sizes, offsets, symbols_out);
+}
+
+// stateful decoder (compressai RansDecoder.set_stream / decode_stream): the autoregressive decoder
+// learns the CDF indexes of a position only after the previous positions are decoded
+extern "C" void* tdvc_rans_decoder_create(const uint8_t* data, int64_t nbytes) {
+  if (!data || nbytes < 8 || (nbytes & 3)) {
+    tdvc_set_error("tdvc_rans_decoder_create: stream must be >= 8 bytes, multiple of 4");
+    return nullptr;
+  }
+  uint8_t* copy = new uint8_t[(size_t)nbytes];
+  memcpy(copy, data, (size_t)nbytes);
+  Dec* dc = new Dec{copy, nbytes / 4, 0, 0, false};
+  const uint64_t lo = dc->word(), hi = dc->word();
+  dc->x = lo | (hi << 32);
+  return dc;
+}
+extern "C" int tdvc_rans_decoder_decode(void* handle, const int32_t* indexes, int64_t n, const int32_t* cdfs,
+                                        int32_t cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets,
+                                        int32_t* symbols_out) {
+  if (!handle || !indexes || !cdfs || !cdf_sizes || !offsets || !symbols_out) {
+    tdvc_set_error("tdvc_rans_decoder_decode: null argument");
+    return TDVC_EINVAL;
+  }
+  return dec_run(*static_cast<Dec*>(handle), indexes, n, cdfs, cdf_stride, cdf_sizes, offsets, symbols_out);
+}
+extern "C" void tdvc_rans_decoder_destroy(void* handle) {
+  if (!handle) return;
+  Dec* dc = static_cast<Dec*>(handle);
+  delete[] dc->d;
+  delete dc;
+}
+
+static int dec_run(Dec& dc, const int32_t* indexes, int64_t n, const int32_t* cdfs, int32_t cdf_stride,
+                   const int32_t* cdf_sizes, const int32_t* offsets, int32_t* symbols_out) {
   const uint32_t mask = (1u << kPrec) - 1;
   for (int64_t i = 0; i < n; ++i) {
     const int32_t ci = indexes[i];
@@ -138,5 +177,44 @@ extern "C" int tdvc_rans_decode(const uint8_t* data, int64_t nbytes, const int32
     if (dc.bad) { tdvc_set_error("tdvc_rans_decode: stream exhausted at symbol %lld", (long long)i); return TDVC_EINVAL; }
     symbols_out[i] = value + offsets[ci];
   }
+  return TDVC_OK;
+}
+
+// compressai `_CXX.pmf_to_quantized_cdf` (cpp_exts/ops/ops.cpp): round to 2^precision, renormalise with
+// integer division, prefix-sum, force the last entry, then repair zero-width bins by stealing one count
+// from the narrowest bin wider than 1.  cdf_out has n + 1 entries.
+extern "C" int tdvc_pmf_to_quantized_cdf(const float* pmf, int n, int precision, int32_t* cdf_out) {
+  if (!pmf || !cdf_out || n < 1 || precision < 1 || precision > 16) {
+    tdvc_set_error("tdvc_pmf_to_quantized_cdf: bad arguments");
+    return TDVC_EINVAL;
+  }
+  std::vector<uint32_t> cdf((size_t)n + 1);
+  cdf[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    const float v = pmf[i] * (float)(1 << precision);
+    cdf[i + 1] = (uint32_t)(v + 0.5f >= 0.f ? (long long)(v + 0.5f) : 0);     // std::round for v >= 0
+    if ((float)cdf[i + 1] - v > 0.5f) cdf[i + 1] -= 1;                          // guard the float add
+  }
+  uint64_t total = 0;
+  for (uint32_t c : cdf) total += c;
+  if (total == 0) { tdvc_set_error("tdvc_pmf_to_quantized_cdf: empty pmf"); return TDVC_EINVAL; }
+  for (auto& c : cdf) c = (uint32_t)((((uint64_t)1 << precision) * c) / total);
+  for (size_t i = 1; i < cdf.size(); ++i) cdf[i] += cdf[i - 1];
+  cdf.back() = 1u << precision;
+  const int m = (int)cdf.size();
+  for (int i = 0; i < m - 1; ++i) {
+    if (cdf[i] == cdf[i + 1]) {
+      uint32_t best_freq = ~0u;
+      int best = -1;
+      for (int j = 0; j < m - 1; ++j) {
+        const uint32_t f = cdf[j + 1] - cdf[j];
+        if (f > 1 && f < best_freq) { best_freq = f; best = j; }
+      }
+      if (best == -1) { tdvc_set_error("tdvc_pmf_to_quantized_cdf: cannot repair zero-width bin"); return TDVC_EINVAL; }
+      if (best < i) { for (int j = best + 1; j <= i; ++j) cdf[j]--; }
+      else { for (int j = i + 1; j <= best; ++j) cdf[j]++; }
+    }
+  }
+  for (int i = 0; i < m; ++i) cdf_out[i] = (int32_t)cdf[i];
   return TDVC_OK;
 }

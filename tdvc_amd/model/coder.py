@@ -309,6 +309,170 @@ class Cheng2020Anchor(nn.Module, PackCache):
     def aux_loss(self):
         return self.entropy_bottleneck.loss()
 
+    # -- entropy coding (`main/model/pnet.py:45-49,69-73`) -----------------------------------
+    @torch.no_grad()
+    def update(self, force=False):
+        """compressai `update(force)`: build the quantised CDF tables of both entropy models.
+        Parameter-space arithmetic (128 x ~60 and 64 x ~3000 values) on the host; CDF quantisation
+        in the C++ coder library."""
+        import scipy.stats
+        dev = self.context_prediction.weight.device
+        eb, gc = self.entropy_bottleneck, self.gaussian_conditional
+        changed = False
+        if gc._offset.numel() == 0 or force:
+            table = torch.exp(torch.linspace(math.log(0.11), math.log(256), 64))
+            mult = -scipy.stats.norm.ppf(gc.tail_mass / 2)
+            center = torch.ceil(table * mult).int()
+            length = 2 * center + 1
+            maxlen = int(length.max())
+            samples = torch.abs(torch.arange(maxlen).int() - center[:, None]).float()
+            sc = table.unsqueeze(1).float()
+            cdfn = lambda v: 0.5 * torch.erfc(-(2 ** -0.5) * v)
+            upper, lower = cdfn((0.5 - samples) / sc), cdfn((-0.5 - samples) / sc)
+            pmf, tail = upper - lower, 2 * lower[:, :1]
+            cdf = torch.zeros((64, maxlen + 2), dtype=torch.int32)
+            for i in range(64):
+                prob = torch.cat((pmf[i, : int(length[i])], tail[i])).numpy()
+                c = ops.pmf_to_quantized_cdf(prob)
+                cdf[i, : c.size] = torch.from_numpy(c)
+            gc._quantized_cdf, gc._offset, gc._cdf_length = cdf.to(dev), (-center).to(dev), (length + 2).to(dev)
+            gc.scale_table = table.to(dev)
+            changed = True
+        if eb._offset.numel() == 0 or force:
+            q = eb.quantiles.detach().float().cpu()
+            med = q[:, 0, 1]
+            minima = torch.clamp(torch.ceil(med - q[:, 0, 0]).int(), min=0)
+            maxima = torch.clamp(torch.ceil(q[:, 0, 2] - med).int(), min=0)
+            start, length = med - minima, maxima + minima + 1
+            maxlen = int(length.max())
+            samples = torch.arange(maxlen)[None, :] + start[:, None, None]
+            ebc = EntropyBottleneck(eb.channels)          # CPU twin for the logits chain
+            ebc.load_state_dict({k: v.cpu() for k, v in eb.state_dict().items()}, strict=False)
+            lower = ebc.logits_cumulative(samples - 0.5, True)
+            upper = ebc.logits_cumulative(samples + 0.5, True)
+            sign = -torch.sign(lower + upper)
+            pmf = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))[:, 0, :]
+            tail = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
+            cdf = torch.zeros((eb.channels, maxlen + 2), dtype=torch.int32)
+            for i in range(eb.channels):
+                prob = torch.cat((pmf[i, : int(length[i])], tail[i])).numpy()
+                c = ops.pmf_to_quantized_cdf(prob)
+                cdf[i, : c.size] = torch.from_numpy(c)
+            eb._quantized_cdf, eb._offset, eb._cdf_length = cdf.to(dev), (-minima).to(dev), (length + 2).to(dev)
+            changed = True
+        self.__dict__.pop("_tables", None)
+        return changed
+
+    def _coder_tables(self):
+        t = self.__dict__.get("_tables")
+        if t is None:
+            eb, gc = self.entropy_bottleneck, self.gaussian_conditional
+            if eb._offset.numel() == 0 or gc._offset.numel() == 0:
+                raise RuntimeError("entropy coder tables are empty: call update(force=True) first (pnet.py:47)")
+            t = (ops.CdfTables(eb._quantized_cdf, eb._cdf_length, eb._offset),
+                 ops.CdfTables(gc._quantized_cdf, gc._cdf_length, gc._offset), gc.scale_table.float().contiguous())
+            self.__dict__["_tables"] = t
+        return t
+
+    def _ctx_1x1(self) -> ops.PackedConv:
+        """the masked 5x5 context conv as a 1x1 conv over gathered 12-tap neighbourhoods"""
+        cp = self.context_prediction
+        def build():
+            w = cp.weight.detach().float().cpu()
+            cols = [w[:, :, dy, dx] for dy, dx in cp.live_taps()]
+            w1 = torch.cat(cols, 1).reshape(w.shape[0], -1, 1, 1)          # (2M, 12*M, 1, 1), tap-major
+            return ops.pack_conv(w1, cp.bias, stride=1, pad=0, device=cp.weight.device)
+        return self._pk("ctx1x1", build)
+
+    @staticmethod
+    def wavefront_steps(H, W):
+        """positions with equal w + 3h are mutually independent under the type-A 5x5 mask"""
+        steps = []
+        for t in range(W + 3 * (H - 1)):
+            ps = [(h, t - 3 * h) for h in range(H) if 0 <= t - 3 * h < W]
+            if ps:
+                steps.append(ps)
+        return steps
+
+    def _ar_step(self, y_hat, params, pos, n, x1, pc):
+        ops.ar_gather(y_hat, params, pos, n, x1, pc)
+        v = lambda fm, c0, C_: FM(fm.t[:, :, :n], c0, 1, C_)
+        ops.conv(v(x1, 0, x1.C), self._ctx_1x1(), out=v(pc, 2 * self.M, 2 * self.M))
+        return self.run_entropy_parameters(v(pc, 0, 4 * self.M))
+
+    @torch.no_grad()
+    def compress(self, x: FM):
+        """-> {"strings": [y_strings, z_strings], "shape": (h, w)} like compressai's compress()"""
+        dev = x.t.device
+        ebt, gct, table = self._coder_tables()
+        M = self.M
+        y32, y16 = self.run_g_a(x)
+        z = self.run_h_a(y16)
+        B, H, W = y32.N, y32.H, y32.W
+        med = self.entropy_bottleneck.quantiles.detach()[:, 0, 1].float().contiguous()
+        zsym = ops.round_symbols(z, med)                                           # (B, h, w, C) int32
+        z_hat = FM((zsym.float() + med).half())
+        params = FM.empty(B, H, W, 2 * M, device=dev)
+        self.run_h_s(z_hat, out=params)
+        zs = zsym.permute(0, 3, 1, 2).contiguous().cpu().numpy()                   # compressai order (C, h, w)
+        zidx = np.broadcast_to(np.arange(M, dtype=np.int32)[:, None, None], zs.shape[1:])
+        z_strings = [ops.rans_encode(zs[b], zidx, ebt) for b in range(B)]
+        steps = self.wavefront_steps(H, W)
+        flat = torch.tensor([p for st in steps for p in st], dtype=torch.int32, device=dev)
+        x1 = FM.empty(1, 1, H, 12 * M, device=dev)
+        pc = FM.empty(1, 1, H, 4 * M, device=dev)
+        y_strings, dbg = [], []
+        for b in range(B):
+            y_hat = FM.zeros(1, H, W, M, device=dev)
+            sym = torch.zeros((H, W, M), dtype=torch.int32, device=dev)
+            idx = torch.zeros((H, W, M), dtype=torch.int32, device=dev)
+            o = 0
+            for st in steps:
+                n = len(st)
+                pos = flat[o:o + n]
+                gp = self._ar_step(y_hat, params.batch(b, 1), pos, n, x1, pc)
+                ops.ar_quantize(y32.batch(b, 1), gp, pos, n, table, y_hat, sym, idx)
+                o += n
+            y_strings.append(ops.rans_encode(sym.cpu().numpy(), idx.cpu().numpy(), gct))      # raster (h, w, c) order
+            dbg.append({"y_hat": y_hat, "symbols": sym, "indexes": idx})
+        return {"strings": [y_strings, z_strings], "shape": (z.H, z.W), "_debug": dbg}
+
+    @torch.no_grad()
+    def decompress(self, strings, shape):
+        """strings as returned by compress(); serial raster-order context decoding (the stream order of
+        compressai's bitstream).  -> {"x_hat": FM, "y_hat": FM}"""
+        dev = self.context_prediction.weight.device
+        ebt, gct, table = self._coder_tables()
+        M = self.M
+        zh, zw = shape
+        B = len(strings[1])
+        H, W = zh * 4, zw * 4
+        med = self.entropy_bottleneck.quantiles.detach()[:, 0, 1].float().contiguous()
+        zidx = np.broadcast_to(np.arange(M, dtype=np.int32)[:, None, None], (M, zh, zw))
+        zs = np.stack([ops.RansDecoder(s).decode(zidx, ebt).reshape(M, zh, zw) for s in strings[1]])
+        zsym = torch.from_numpy(zs).to(dev).permute(0, 2, 3, 1).contiguous()
+        z_hat = FM((zsym.float() + med).half())
+        params = FM.empty(B, H, W, 2 * M, device=dev)
+        self.run_h_s(z_hat, out=params)
+        x1 = FM.empty(1, 1, 1, 12 * M, device=dev)
+        pc = FM.empty(1, 1, 1, 4 * M, device=dev)
+        y_hat_all = FM.zeros(B, H, W, M, device=dev)
+        sym = torch.zeros((H, W, M), dtype=torch.int32, device=dev)
+        idx = torch.zeros((H, W, M), dtype=torch.int32, device=dev)
+        for b in range(B):
+            dec = ops.RansDecoder(strings[0][b])
+            y_hat = y_hat_all.batch(b, 1)
+            for h in range(H):
+                for w in range(W):
+                    pos = torch.tensor([[h, w]], dtype=torch.int32, device=dev)
+                    gp = self._ar_step(y_hat, params.batch(b, 1), pos, 1, x1, pc)
+                    ops.ar_indexes(gp, pos, 1, table, M, W, idx)
+                    q = dec.decode(idx[h, w].cpu().numpy(), gct)
+                    sym[h, w] = torch.from_numpy(q).to(dev)
+                    ops.ar_quantize(None, gp, pos, 1, table, y_hat, sym, idx, symbols_in=sym)
+            dec.close()
+        return {"x_hat": self.run_g_s(y_hat_all), "y_hat": y_hat_all}
+
 
 def _g_a(N):
     return nn.Sequential(

@@ -66,12 +66,17 @@ class VideoCompressor(nn.Module):
             iframe8 = ops.from_nchw(refer_frames[:, 0].float(), Cpad=8)
 
             feats = FM.empty(B, H, W, 192, device=dev)                   # [f_cur | f_ref | dcn_out]
+            npx_ = float(B * H * W)
             f_cur = self.extra_fea.run(cur8, feats.ch(0, 64))
             self.extra_fea.run(ref8, feats.ch(64, 64))
             estmv = self.motion_est.run(feats, cur32, ref32)
 
             tr_mv = {} if trace is not None else None
             mv_hat, mv_bits = self.mvCoder.run(estmv, training=False, trace=tr_mv)
+            coded = {}
+            if is_compress:                                      # pnet.py:45-49
+                self.mvCoder.update(force=True)
+                coded["mv"] = self.mvCoder.compress(estmv)
 
             xt = FM.empty(B, H, W, 256, device=dev)                      # 4 frames x 64 ch
             pred1 = self.mcnet.run(mv_hat, feats, xt.ch(192, 64))
@@ -81,6 +86,12 @@ class VideoCompressor(nn.Module):
 
             tr_res = {} if trace is not None else None
             recon_f, res_bits = self.resCoder.run(resid, training=False, res=pred, trace=tr_res)
+            if is_compress:                                      # pnet.py:69-73
+                self.resCoder.update(force=True)
+                coded["res"] = self.resCoder.compress(resid)
+                # the reference computes these and drops them (pnet.py:49,73); kept for inspection
+                self.last_strings = {k: v["strings"] for k, v in coded.items()}
+                self.last_ac_bpp = {k: sum(len(s[0]) for s in v["strings"]) * 8.0 / npx_ for k, v in coded.items()}
 
             recon = self.loopfilter.run(recon_f, iframe8, training=False, trace=trace)
 

@@ -33,15 +33,23 @@ class FM:
     """Feature-map view over a torch buffer `t` of shape (N, H, W, Cbuf): N images of C channels
     starting `off` elements into the buffer, batch stride `sn`, pixel stride t.stride(2)."""
 
-    __slots__ = ("t", "off", "N", "C", "H", "W", "sn")
+    __slots__ = ("t", "off", "N", "C", "H", "W", "sn", "sp")
 
     def __init__(self, t: torch.Tensor, off: int = 0, N: int | None = None, C_: int | None = None, sn: int | None = None):
-        assert t.dim() == 4 and t.stride(3) == 1 and t.stride(1) == t.shape[2] * t.stride(2)
+        assert t.dim() == 4 and (t.shape[3] == 1 or t.stride(3) == 1)
         self.t, self.off = t, off
         self.N = t.shape[0] if N is None else N
         self.C = t.shape[3] if C_ is None else C_
         self.H, self.W = t.shape[1], t.shape[2]
-        self.sn = t.stride(0) if sn is None else sn
+        # strides of size-1 dimensions are arbitrary in torch: derive them from the dense layout instead
+        if self.W > 1:
+            self.sp = t.stride(2)
+        elif self.H > 1:
+            self.sp = t.stride(1)
+        else:
+            self.sp = t.shape[3]
+        assert self.H == 1 or t.stride(1) == self.W * self.sp, "rows of a feature map must be dense (row stride = W * pixel stride)"
+        self.sn = (t.stride(0) if t.shape[0] > 1 else self.H * self.W * self.sp) if sn is None else sn
 
     @staticmethod
     def empty(N, H, W, C_, dtype=torch.float16, device="cuda"):
@@ -71,8 +79,7 @@ class FM:
 
     def desc(self) -> L.FMapDesc:
         p = self.t.data_ptr() + self.off * self.t.element_size()
-        return L.FMapDesc(p, self.N, self.H, self.W, self.C, self.sn, self.t.stride(2),
-                          L.F32 if self.f32 else L.F16)
+        return L.FMapDesc(p, self.N, self.H, self.W, self.C, self.sn, self.sp, L.F32 if self.f32 else L.F16)
 
     def to_nchw(self, C_=None) -> torch.Tensor:
         C_ = self.C if C_ is None else C_
@@ -380,6 +387,85 @@ def quantize(y: FM, out: FM, noise: FM | None = None) -> FM:
     dy, do = y.desc(), out.desc()
     dn = noise.desc() if noise is not None else None
     L.check(L.lib().tdvc_quantize(C.byref(dy), C.byref(dn) if dn is not None else None, C.byref(do), _stream()), "quantize")
+    return out
+
+
+# ----------------------------------------------------------------------------- entropy coding (host + AR kernels)
+def pmf_to_quantized_cdf(pmf: np.ndarray, precision: int = 16) -> np.ndarray:
+    p = np.ascontiguousarray(pmf, dtype=np.float32)
+    out = np.zeros(p.size + 1, dtype=np.int32)
+    L.check(L.lib().tdvc_pmf_to_quantized_cdf(p.ctypes.data, p.size, precision, out.ctypes.data), "pmf_to_quantized_cdf")
+    return out
+
+
+class CdfTables:
+    """host copies of an entropy model's quantised CDFs in the layout the range coder takes"""
+
+    def __init__(self, cdf: torch.Tensor, lengths: torch.Tensor, offsets: torch.Tensor):
+        self.cdf = np.ascontiguousarray(cdf.detach().cpu().numpy(), dtype=np.int32)
+        self.sizes = np.ascontiguousarray(lengths.detach().cpu().numpy().reshape(-1), dtype=np.int32)
+        self.offsets = np.ascontiguousarray(offsets.detach().cpu().numpy().reshape(-1), dtype=np.int32)
+        self.stride = self.cdf.shape[1]
+
+
+def rans_encode(symbols: np.ndarray, indexes: np.ndarray, t: CdfTables) -> bytes:
+    s = np.ascontiguousarray(symbols.reshape(-1), dtype=np.int32)
+    i = np.ascontiguousarray(indexes.reshape(-1), dtype=np.int32)
+    out = np.empty(4 * s.size + 64, dtype=np.uint8)
+    n = L.lib().tdvc_rans_encode(s.ctypes.data, i.ctypes.data, s.size, t.cdf.ctypes.data, t.stride, t.sizes.ctypes.data,
+                                 t.offsets.ctypes.data, out.ctypes.data, out.size)
+    if n < 0:
+        L.check(int(n), "rans_encode")
+    return out[:n].tobytes()
+
+
+class RansDecoder:
+    def __init__(self, data: bytes):
+        self._buf = np.frombuffer(data, dtype=np.uint8)
+        self._h = L.lib().tdvc_rans_decoder_create(self._buf.ctypes.data, self._buf.size)
+        if not self._h:
+            L.check(-1, "rans_decoder_create")
+
+    def decode(self, indexes: np.ndarray, t: CdfTables) -> np.ndarray:
+        i = np.ascontiguousarray(indexes.reshape(-1), dtype=np.int32)
+        out = np.empty(i.size, dtype=np.int32)
+        L.check(L.lib().tdvc_rans_decoder_decode(self._h, i.ctypes.data, i.size, t.cdf.ctypes.data, t.stride,
+                                                 t.sizes.ctypes.data, t.offsets.ctypes.data, out.ctypes.data), "rans_decode")
+        return out
+
+    def close(self):
+        if self._h:
+            L.lib().tdvc_rans_decoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def ar_gather(y_hat: FM, params: FM, pos: torch.Tensor, npos: int, x1: FM, pc: FM):
+    dy, dp, dx, dc = y_hat.desc(), params.desc(), x1.desc(), pc.desc()
+    L.check(L.lib().tdvc_ar_gather(C.byref(dy), C.byref(dp), pos.data_ptr(), npos, C.byref(dx), C.byref(dc), _stream()), "ar_gather")
+
+
+def ar_quantize(y: FM | None, gp: FM, pos: torch.Tensor, npos: int, table: torch.Tensor, y_hat: FM, symbols: torch.Tensor,
+                indexes: torch.Tensor, symbols_in: torch.Tensor | None = None):
+    dg, dh = gp.desc(), y_hat.desc()
+    dy = y.desc() if y is not None else None
+    L.check(L.lib().tdvc_ar_quantize(C.byref(dy) if dy is not None else None, C.byref(dg), pos.data_ptr(), npos, table.data_ptr(),
+                                     table.numel(), symbols_in.data_ptr() if symbols_in is not None else None, C.byref(dh),
+                                     symbols.data_ptr(), indexes.data_ptr(), _stream()), "ar_quantize")
+
+
+def ar_indexes(gp: FM, pos: torch.Tensor, npos: int, table: torch.Tensor, M: int, W: int, indexes: torch.Tensor):
+    dg = gp.desc()
+    L.check(L.lib().tdvc_ar_indexes(C.byref(dg), pos.data_ptr(), npos, table.data_ptr(), table.numel(), M, W,
+                                    indexes.data_ptr(), _stream()), "ar_indexes")
+
+
+def round_symbols(z: FM, median: torch.Tensor) -> torch.Tensor:
+    out = torch.empty((z.N, z.H, z.W, z.C), dtype=torch.int32, device=z.t.device)
+    dz = z.desc()
+    L.check(L.lib().tdvc_round_symbols(C.byref(dz), median.data_ptr(), out.data_ptr(), _stream()), "round_symbols")
     return out
 
 

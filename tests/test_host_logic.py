@@ -64,6 +64,12 @@ def test_fm_views_address_arithmetic():
     assert d.p == base + 4 * 6 * 256 * 2 and d.N == 4 and d.sn == 64 and d.C == 64 and d.sp == 256
     d = s.batch(1, 3).desc()
     assert d.p == base + (4 * 6 * 256 + 64) * 2 and d.N == 3
+    # size-1 dimensions carry arbitrary torch strides (e.g. after permute): FM must not trust them
+    odd = torch.zeros(1, 128, 1, 1, dtype=torch.float16).permute(0, 2, 3, 1)
+    d = ops.FM(odd).desc()
+    assert d.sp == 128 and d.sn == 128 and d.C == 128
+    nar = ops.FM(torch.zeros(1, 1, 8, 64, dtype=torch.float16)[:, :, :3])
+    assert nar.W == 3 and nar.desc().sp == 64
     f32 = ops.FM(torch.zeros(1, 2, 2, 4))
     assert f32.f32 and f32.desc().dtype == 1
 
