@@ -112,56 +112,18 @@ inline float conv_simple_slope(const ConvParams& p) {
 // through a wave-private LDS region `ew` (32 x 144 B), then every lane owns 8 consecutive channels of a
 // pixel, so aux / residuals / output move as full 128-byte lines (8 lanes x 16 B per pixel).  All loads
 // of a pass are issued before any is consumed (one memory round trip per pass).
+// --- the two halves of the transposed epilogue ------------------------------------------------------
+// (1) pack: bias + activation in the MFMA layout -> fp16, 4 consecutive channels per (mt, g) slot.
+struct PackedRow { half4 v[8]; };           // [mt*4 + g] -> channels mt*32 + 8g + 4*(lane>>5) .. +3
+
 template <int NTX>
-__device__ __forceinline__ void epilogue_simple_rows(const ConvParams& p, f32x16 (&acc)[2][NTX], const float* bias64,
-                                                     unsigned char* ew, int n, int cbase, int oy_first, int ox_first,
-                                                     int lane, bool zero_acc) {
-  constexpr int EPS = 144;
-  const int hh = lane >> 5, r = lane & 31;
-  const int chunk = lane & 7, prow = lane >> 3;
-  const int co = cbase + chunk * 8;
-  const bool has1 = p.res.p != nullptr, has2 = p.res2.p != nullptr, gdn = p.gdn != 0;
-  // output geometry: plain NHWC or PixelShuffle(2) (host permutes rows: packed = (i*2+j)*cq + c)
-  int pc = co, sub_y = 0, sub_x = 0, mul = 1, PW = p.Wo;
-  if (p.out_mode == TDVC_OUT_SHUFFLE2) {
-    const int cq = p.cout >> 2;
-    const int sub = co / cq;
-    pc = co - sub * cq;
-    sub_y = sub >> 1; sub_x = sub & 1; mul = 2; PW = 2 * p.Wo;
-  }
-  const bool ch_ok = pc < p.y.C && co < ((p.cout + 63) & ~63);
+__device__ __forceinline__ void epilogue_pack(const ConvParams& p, f32x16 (&acc)[2][NTX], const float* bias64, int lane,
+                                              PackedRow (&out)[NTX], bool zero_acc) {
+  const int hh = lane >> 5;
 #pragma unroll
-  for (int nt = 0; nt < NTX; ++nt) {
-    const int oy = oy_first + nt;
-    const bool row_ok = oy < p.Ho && ch_ok;
-    half8 r0[4], r1[4], r2[4];
-    long opix[4], apix[4];
-    bool ok[4];
+  for (int nt = 0; nt < NTX; ++nt)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int ox = ox_first + k * 8 + prow;
-      ok[k] = row_ok && ox < p.Wo;
-      opix[k] = ok[k] ? (long)(mul * oy + sub_y) * PW + (mul * ox + sub_x) : 0;
-      apix[k] = ok[k] ? (long)oy * p.Wo + ox : 0;
-    }
-    const int pcc = ch_ok ? pc : 0;
-    if (gdn) {
-      const half_t* ab = reinterpret_cast<const half_t*>(p.aux.p) + (long)n * p.aux.sn + (ch_ok ? co : 0);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) r0[k] = *reinterpret_cast<const half8*>(ab + apix[k] * p.aux.sp);
-    }
-    if (has1) {
-      const half_t* rb = reinterpret_cast<const half_t*>(p.res.p) + (long)n * p.res.sn + pcc;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) r1[k] = *reinterpret_cast<const half8*>(rb + opix[k] * p.res.sp);
-    }
-    if (has2) {
-      const half_t* rb = reinterpret_cast<const half_t*>(p.res2.p) + (long)n * p.res2.sn + pcc;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) r2[k] = *reinterpret_cast<const half8*>(rb + opix[k] * p.res2.sp);
-    }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int cl = mt * 32 + 8 * g + 4 * hh;
@@ -174,12 +136,66 @@ __device__ __forceinline__ void epilogue_simple_rows(const ConvParams& p, f32x16
           v = v > 0.f ? v : v * p.slope;
           o[i] = (half_t)v;
         }
-        *reinterpret_cast<half4*>(ew + r * EPS + cl * 2) = o;
+        out[nt].v[mt * 4 + g] = o;
       }
+}
+
+// (2) store one output row (32 pixels x 64 channels of this wave) through the wave-private LDS region
+// `ew` (32 x 144 B): afterwards every lane owns 8 consecutive channels of a pixel, so GDN multiplicand,
+// residuals and the output move as full 128-byte lines; all loads are issued before any is consumed.
+__device__ __forceinline__ void epilogue_store_row(const ConvParams& p, const PackedRow& row, unsigned char* ew, int n, int cbase,
+                                                   int oy, int ox_first, int lane) {
+  constexpr int EPS = 144;
+  const int hh = lane >> 5, r = lane & 31;
+  const int chunk = lane & 7, prow = lane >> 3;
+  const int co = cbase + chunk * 8;
+  const bool has1 = p.res.p != nullptr, has2 = p.res2.p != nullptr, gdn = p.gdn != 0;
+  int pc = co, sub_y = 0, sub_x = 0, mul = 1, PW = p.Wo;
+  if (p.out_mode == TDVC_OUT_SHUFFLE2) {     // host permutes rows: packed = (i*2+j)*cq + c
+    const int cq = p.cout >> 2;
+    const int sub = co / cq;
+    pc = co - sub * cq;
+    sub_y = sub >> 1; sub_x = sub & 1; mul = 2; PW = 2 * p.Wo;
+  }
+  const bool ch_ok = pc < p.y.C && co < ((p.cout + 63) & ~63);
+  const bool row_ok = oy < p.Ho && ch_ok;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<half4*>(ew + r * EPS + (mt * 32 + 8 * g + 4 * hh) * 2) = row.v[mt * 4 + g];
+  const int pcc = ch_ok ? pc : 0;
+  constexpr int KB = 4;                         // pixel groups per load batch (all four: one round trip per row)
+#pragma unroll
+  for (int k0 = 0; k0 < 4; k0 += KB) {
+    half8 r0[KB], r1[KB], r2[KB];
+    long opix[KB], apix[KB];
+    bool ok[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int ox = ox_first + (k0 + k) * 8 + prow;
+      ok[k] = row_ok && ox < p.Wo;
+      opix[k] = ok[k] ? (long)(mul * oy + sub_y) * PW + (mul * ox + sub_x) : 0;
+      apix[k] = ok[k] ? (long)oy * p.Wo + ox : 0;
+    }
+    if (gdn) {
+      const half_t* ab = reinterpret_cast<const half_t*>(p.aux.p) + (long)n * p.aux.sn + (ch_ok ? co : 0);
+#pragma unroll
+      for (int k = 0; k < KB; ++k) r0[k] = *reinterpret_cast<const half8*>(ab + apix[k] * p.aux.sp);
+    }
+    if (has1) {
+      const half_t* rb = reinterpret_cast<const half_t*>(p.res.p) + (long)n * p.res.sn + pcc;
+#pragma unroll
+      for (int k = 0; k < KB; ++k) r1[k] = *reinterpret_cast<const half8*>(rb + opix[k] * p.res.sp);
+    }
+    if (has2) {
+      const half_t* rb = reinterpret_cast<const half_t*>(p.res2.p) + (long)n * p.res2.sn + pcc;
+#pragma unroll
+      for (int k = 0; k < KB; ++k) r2[k] = *reinterpret_cast<const half8*>(rb + opix[k] * p.res2.sp);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      half8 h = *reinterpret_cast<const half8*>(ew + (k * 8 + prow) * EPS + chunk * 16);
+    for (int k = 0; k < KB; ++k) {
+      half8 h = *reinterpret_cast<const half8*>(ew + ((k0 + k) * 8 + prow) * EPS + chunk * 16);
       if (gdn || has1 || has2) {
         float v[8];
 #pragma unroll
@@ -202,6 +218,17 @@ __device__ __forceinline__ void epilogue_simple_rows(const ConvParams& p, f32x16
       if (ok[k]) *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.y.p) + (long)n * p.y.sn + opix[k] * p.y.sp + pc) = h;
     }
   }
+}
+
+// immediate form used by conv_mfma (v1), v2 and v3
+template <int NTX>
+__device__ __forceinline__ void epilogue_simple_rows(const ConvParams& p, f32x16 (&acc)[2][NTX], const float* bias64,
+                                                     unsigned char* ew, int n, int cbase, int oy_first, int ox_first,
+                                                     int lane, bool zero_acc) {
+  PackedRow rows[NTX];
+  epilogue_pack<NTX>(p, acc, bias64, lane, rows, zero_acc);
+#pragma unroll
+  for (int nt = 0; nt < NTX; ++nt) epilogue_store_row(p, rows[nt], ew, n, cbase, oy_first + nt, ox_first, lane);
 }
 
 }  // namespace convk
