@@ -86,9 +86,32 @@ def cpu_baseline(sample_hw=(512, 960)):
             "sample": f"1 P-frame forward of the fp32 PyTorch oracle at {h}x{w} ({frac:.3f} of the 1088x1920 pixels), fps scaled by area"}
 
 
+REP_LAUNCH = dict(cin=64, cout=64, k=3, H=HP, W=WP)      # the layer shape behind most conv_mfma_v4 launches
+
+
+def pmc_traffic_bytes():
+    """HBM bytes per representative launch from the committed rocprofv3 --pmc summary (separate FETCH_SIZE /
+    WRITE_SIZE passes; gfx950 correction: wide coalesced reads report half -> 2 x FETCH_SIZE)."""
+    f = os.path.join(ROOT, "profiles", "r01_v4_conv3x3_64_64_1080p_pmc.txt")
+    if not os.path.exists(f):
+        return None
+    vals = {}
+    for ln in open(f):
+        parts = ln.split()
+        if len(parts) == 2:
+            try:
+                vals[parts[0]] = float(parts[1])
+            except ValueError:
+                pass
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
 def roofline_leg(runner):
-    """one extra P-frame with HIP events around every conv launch (torch's current stream is the
-    launch stream).  Dominant kernel = the MFMA conv instantiation with the largest total time."""
+    """(1) one extra P-frame with HIP events around every conv launch (torch's current stream IS the launch
+    stream) -> per-instantiation table; (2) the dominant kernel's representative launch (3x3 64->64 at
+    1088x1920, 154 GFLOP algorithmic, 535 MB algorithmic) timed live over 20 launches."""
     from tdvc_amd import ops
     ops.PROFILE = []
     runner.step()
@@ -103,10 +126,30 @@ def roofline_leg(runner):
     name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
     tot_ms = sum(v["ms"] for v in agg.values())
     tot_fl = sum(v["flops"] for v in agg.values())
-    ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s",
-            "frac": round(ach * 1e12 / MFMA_F16_PEAK, 4), "traffic": None, "launches_per_frame": a["n"],
-            "avg_launch_ms": round(a["ms"] / a["n"], 4), "kernel_ms_per_frame": round(a["ms"], 3),
+    # representative launch
+    L = REP_LAUNCH
+    x = ops.FM(torch.randn(1, L["H"], L["W"], L["cin"], device="cuda").half())
+    pc = ops.pack_conv(torch.randn(L["cout"], L["cin"], L["k"], L["k"]) * 0.04, torch.zeros(L["cout"]), stride=1, pad=1)
+    y = ops.conv(x, pc, act=ops.ACT_RELU)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.conv(x, pc, out=y, act=ops.ACT_RELU)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    flop = 2.0 * L["H"] * L["W"] * L["cout"] * L["cin"] * L["k"] ** 2
+    alg_bytes = 2.0 * L["H"] * L["W"] * (L["cin"] + L["cout"])
+    ach = flop / (ms * 1e-3) / 1e12
+    traffic = pmc_traffic_bytes()
+    return {"bound": "mfma", "kernel": name, "launch": "3x3 64->64 stride 1 @1088x1920 (154.0 GFLOP, 534.8 MB algorithmic)",
+            "achieved": round(ach, 2), "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / MFMA_F16_PEAK, 4),
+            "avg_launch_ms": round(ms, 4), "traffic": traffic,
+            "hbm_side": {"algorithmic_GBps": round(alg_bytes / (ms * 1e-3) / 1e9, 1), "peak_GBps": 8000.0,
+                         "frac": round(alg_bytes / (ms * 1e-3) / 8e12, 4)},
+            "frame_kernel": {"launches_per_frame": a["n"], "ms_per_frame": round(a["ms"], 3),
+                             "tflops": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2)},
             "all_conv_ms_per_frame": round(tot_ms, 3), "all_conv_tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
             "by_kernel": {k: {"ms": round(v["ms"], 3), "n": v["n"], "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
                           for k, v in sorted(agg.items())}}
