@@ -48,8 +48,8 @@ class VideoCompressor(nn.Module):
     def forward(self, input_image, refer_frames, enabled_amp=True, is_compress=False, trace=None):
         if not (input_image.is_cuda and refer_frames.is_cuda):
             raise RuntimeError("tdvc_amd.VideoCompressor runs on a HIP device only (no CPU fallback)")
-        if self.training:
-            raise NotImplementedError("training-mode forward (noise quantisation + autograd) lands with the backward kernels")
+        training = self.training       # noise quantisation, scale-8 matching, 5-tuple return (pnet.py:80-83); the
+        # outputs carry no autograd graph yet: the backward kernels are not built
         B, _, H, W = input_image.shape
         if H % 64 or W % 64:
             raise RuntimeError(f"input must be padded to a multiple of 64 (got {H}x{W}); see tools/predict.py:51-53")
@@ -72,7 +72,7 @@ class VideoCompressor(nn.Module):
             estmv = self.motion_est.run(feats, cur32, ref32)
 
             tr_mv = {} if trace is not None else None
-            mv_hat, mv_bits = self.mvCoder.run(estmv, training=False, trace=tr_mv)
+            mv_hat, mv_bits = self.mvCoder.run(estmv, training=training, trace=tr_mv)
             coded = {}
             if is_compress:                                      # pnet.py:45-49
                 self.mvCoder.update(force=True)
@@ -85,7 +85,7 @@ class VideoCompressor(nn.Module):
             resid = ops.scale_act_res(f_cur, FM.empty(B, H, W, 64, device=dev), res=pred, res_sign=-1.0)
 
             tr_res = {} if trace is not None else None
-            recon_f, res_bits = self.resCoder.run(resid, training=False, res=pred, trace=tr_res)
+            recon_f, res_bits = self.resCoder.run(resid, training=training, res=pred, trace=tr_res)
             if is_compress:                                      # pnet.py:69-73
                 self.resCoder.update(force=True)
                 coded["res"] = self.resCoder.compress(resid)
@@ -93,7 +93,7 @@ class VideoCompressor(nn.Module):
                 self.last_strings = {k: v["strings"] for k, v in coded.items()}
                 self.last_ac_bpp = {k: sum(len(s[0]) for s in v["strings"]) * 8.0 / npx_ for k, v in coded.items()}
 
-            recon = self.loopfilter.run(recon_f, iframe8, training=False, trace=trace)
+            recon = self.loopfilter.run(recon_f, iframe8, training=training, trace=trace)
 
             npx = float(B * H * W)
             bpp_mv = (mv_bits.sum() / npx).float().view(-1)
@@ -101,4 +101,6 @@ class VideoCompressor(nn.Module):
             if trace is not None:
                 trace.update(f_cur=f_cur, f_ref=feats.ch(64, 64), estmv=estmv, mv_x_hat=mv_hat, pred1=pred1, pred=pred,
                              resid=resid, recon_f=recon_f, mv=tr_mv, res=tr_res)
+        if training:
+            return recon, bpp_res, bpp_mv, self.mvCoder.aux_loss(), self.resCoder.aux_loss()
         return recon, bpp_res, bpp_mv

@@ -109,3 +109,34 @@ def test_module_api(models):
         m(x, torch.zeros(1, 4, 3, 60, 64).cuda(), True)
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 64, 64), torch.zeros(1, 4, 3, 64, 64), True)
+
+
+def test_training_mode_forward(models, report):
+    """`.train()` forward: additive-noise quantisation, FeatureFix scale 8, 5-tuple return
+    (pnet.py:80-83).  With the noise drawn from U(-0.5, 0.5) both paths are stochastic, so the
+    comparison is statistical: rate and distortion of the GPU path must sit within the spread of the
+    oracle's own seeds.  (No autograd graph yet: backward kernels are a later round.)"""
+    from tdvc_amd.synth import make_gop, ref_list
+    ref, m = models
+    g = make_gop(1234, 2, 128, 192)
+    refs = ref_list([g[0:1]])
+    ref.train(); m.train()
+    try:
+        o_bpp, o_mse = [], []
+        with torch.no_grad():
+            for seed in range(3):
+                torch.manual_seed(seed)
+                ro, bro, bmo, a1, a2 = ref(g[1:2], refs, False)
+                o_bpp.append(float(bro + bmo)); o_mse.append(float(((ro - g[1:2]) ** 2).mean()))
+            torch.manual_seed(7)
+            out = m(g[1:2].cuda(), refs.cuda(), True)
+        assert len(out) == 5
+        rg, brg, bmg, ag1, ag2 = out
+        g_bpp, g_mse = float(brg + bmg), float(((rg.cpu() - g[1:2]) ** 2).mean())
+        report(f"train-mode forward: bpp oracle seeds {o_bpp} gpu {g_bpp:.4f}; mse oracle {o_mse} gpu {g_mse:.5f}; "
+               f"aux {float(a1):.3f}/{float(ag1):.3f}")
+        mb, mm = sum(o_bpp) / 3, sum(o_mse) / 3
+        assert abs(g_bpp - mb) < 0.03 * mb and abs(g_mse - mm) < 0.05 * mm
+        assert abs(float(ag1) - float(a1)) < 1e-3 * abs(float(a1)) + 1e-3 and abs(float(ag2) - float(a2)) < 1e-3 * abs(float(a2)) + 1e-3
+    finally:
+        ref.eval(); m.eval()
