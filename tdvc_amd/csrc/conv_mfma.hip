@@ -24,6 +24,8 @@ int launch_conv_v3(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
 bool conv_v3_eligible(const tdvc_conv_desc* d, int Ho, int Wo);
 int launch_conv_v4(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
 bool conv_v4_eligible(const tdvc_conv_desc* d, int Ho, int Wo);
+int launch_conv_v5(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
+bool conv_v5_eligible(const tdvc_conv_desc* d, int Ho, int Wo);
 
 namespace {
 
@@ -326,6 +328,7 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
     TDVC_CHECK(conv_v3_eligible(d, Ho, Wo), "tdvc_conv2d: s2d conv not eligible for the stage-pipelined kernel");
     return launch_conv_v3(p, tiles / 2, d->x.N, reinterpret_cast<hipStream_t>(stream));
   }
+  if (conv_v5_eligible(d, Ho, Wo)) return launch_conv_v5(p, tiles / 2, d->x.N, reinterpret_cast<hipStream_t>(stream));
   if (conv_v4_eligible(d, Ho, Wo)) return launch_conv_v4(p, tiles / 2, d->x.N, reinterpret_cast<hipStream_t>(stream));
   if (conv_v3_eligible(d, Ho, Wo)) return launch_conv_v3(p, tiles / 2, d->x.N, reinterpret_cast<hipStream_t>(stream));
   if (conv_v2_eligible(d, Ho, Wo)) return launch_conv_v2(p, 0, tiles / 2, d->x.N, reinterpret_cast<hipStream_t>(stream));

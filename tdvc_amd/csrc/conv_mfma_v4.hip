@@ -81,17 +81,14 @@ __global__ __launch_bounds__(NTHR, 1) void conv_mfma_v4_kernel(const ConvParams 
   const int c8off = (tid & 3) * 8;
   const half_t* xn = p.x + (long)n * p.x_sn;
 
-  // Depth-2 prefetch with HAND-COUNTED waits.  Two register sets; set (S&1) is loaded two stages
-  // ahead.  The loads are inline asm, so hipcc's own vmcnt bookkeeping does not see them (its waits
-  // for other loads can only over-wait, which is safe) and the wait is ours: issue(S+2) is the LAST
-  // vector-memory work of stage S, so at the top of stage S+1 the TLOADS4 youngest outstanding
-  // operations are exactly set S+2 and `s_waitcnt vmcnt(TLOADS4)` retires set S+1 (and everything
-  // older, e.g. the epilogue stores) while leaving a full stage of tile loads (40 KB per CU) in
-  // flight.  Little: the HBM fair share of ~10 B/clk/CU needs ~50 KB outstanding at loaded latency;
-  // one burst per stage averaged ~20 KB and measured 4.3 B/clk/CU.
-  // Loads are unconditional (clamped address); out-of-image items are zero-selected at publish time.
-  u32x4 treg[2][TLOADS4];
-  unsigned okmask[2] = {0u, 0u};
+  // Prefetch: the next stage's tile loads are issued right after this stage is published and stay in
+  // flight during the whole matrix phase (plain, compiler-tracked loads).  A depth-2 variant with
+  // hand-counted inline-asm loads measured 4 % faster, but asm loads leave their destination registers
+  // "valid" to the register allocator before the data has landed — a copy or spill in that window reads
+  // stale data (seen once in a sibling kernel) — so it is not used.  Out-of-image items are
+  // zero-selected at publish time.
+  u32x4 treg[1][TLOADS4];
+  unsigned okmask[1] = {0u};
   auto issue = [&](auto setc, int S) {
     constexpr int SET = decltype(setc)::value;
     const int tile_i = S / nchunks, ch = S - tile_i * nchunks;
@@ -108,13 +105,12 @@ __global__ __launch_bounds__(NTHR, 1) void conv_mfma_v4_kernel(const ConvParams 
       const bool ok = cok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
       const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
       const half_t* src = xn + ((long)iyc * p.W + ixc) * p.x_sp + cgc;
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(treg[SET][j]) : "v"(src) : "memory");
+      treg[SET][j] = *reinterpret_cast<const u32x4*>(src);
       m |= (ok ? 1u : 0u) << j;
     }
     okmask[SET] = m;
   };
   using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
 
   int base[NT4];
 #pragma unroll
@@ -132,16 +128,10 @@ __global__ __launch_bounds__(NTHR, 1) void conv_mfma_v4_kernel(const ConvParams 
   // would prefetch / store in the same instant and HBM would alternate between overload and idle.
   for (int i = 0; i < (int)(blockIdx.x & 3) * e.stagger; ++i) __builtin_amdgcn_s_sleep(32);
   issue(I0{}, 0);
-  if (nstages > 1) issue(I1{}, 1);
   auto stage = [&](auto setc, int S) {
     constexpr int SET = decltype(setc)::value;
     const int tile_i = S / nchunks, ch = S - tile_i * nchunks;
     ST4(0);
-    static_assert(TLOADS4 == 5, "the wait below names 5 registers / counts 5 loads");
-    if (S + 1 < nstages)
-      asm volatile("s_waitcnt vmcnt(5)" : "+v"(treg[SET][0]), "+v"(treg[SET][1]), "+v"(treg[SET][2]), "+v"(treg[SET][3]), "+v"(treg[SET][4]) : : "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(treg[SET][0]), "+v"(treg[SET][1]), "+v"(treg[SET][2]), "+v"(treg[SET][3]), "+v"(treg[SET][4]) : : "memory");
     __syncthreads();                     // previous stage's reads / epilogue scratch done (and, at S = 0, weights visible after the next barrier)
     ST4(1);
 #pragma unroll
@@ -158,6 +148,7 @@ __global__ __launch_bounds__(NTHR, 1) void conv_mfma_v4_kernel(const ConvParams 
     ST4(2);
     __syncthreads();
     ST4(3);
+    if (S + 1 < nstages) issue(setc, S + 1);      // in flight during the matrix phase
     ST4(4);
 
     const unsigned char* wch = wlds + ch * ntaps * WSL4 + lane * 16;
@@ -180,10 +171,7 @@ __global__ __launch_bounds__(NTHR, 1) void conv_mfma_v4_kernel(const ConvParams 
     }
 
     ST4(5);
-    if (ch != nchunks - 1) {
-      if (S + 2 < nstages) issue(setc, S + 2);
-      return;
-    }
+    if (ch != nchunks - 1) return;
     const int tile = first + tile_i * stride;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     if constexpr (SIMPLE) {
@@ -208,7 +196,6 @@ __global__ __launch_bounds__(NTHR, 1) void conv_mfma_v4_kernel(const ConvParams 
         }
       }
     }
-    if (S + 2 < nstages) issue(setc, S + 2);          // last vector-memory work of the stage (see the wait above)
     ST4(6);
     if constexpr (STAMP) {
       if (S == 3 && threadIdx.x == 0) {
@@ -217,10 +204,7 @@ __global__ __launch_bounds__(NTHR, 1) void conv_mfma_v4_kernel(const ConvParams 
       }
     }
   };
-  for (int S = 0; S < nstages; S += 2) {
-    stage(I0{}, S);
-    if (S + 1 < nstages) stage(I1{}, S + 1);
-  }
+  for (int S = 0; S < nstages; ++S) stage(I0{}, S);
 }
 
 inline int v4_tile_bytes(int kh, int kw) { return (TH4 + kh - 1) * (TW4 + kw - 1) * PS4; }
