@@ -86,13 +86,13 @@ def cpu_baseline(sample_hw=(512, 960)):
             "sample": f"1 P-frame forward of the fp32 PyTorch oracle at {h}x{w} ({frac:.3f} of the 1088x1920 pixels), fps scaled by area"}
 
 
-REP_LAUNCH = dict(cin=64, cout=64, k=3, H=HP, W=WP)      # the layer shape behind most conv_mfma_v4 launches
+REP_LAUNCH = dict(cin=64, cout=64, k=3, H=HP, W=WP)      # the layer shape behind most launches of the dominant kernel
 
 
 def pmc_traffic_bytes():
     """HBM bytes per representative launch from the committed rocprofv3 --pmc summary (separate FETCH_SIZE /
     WRITE_SIZE passes; gfx950 correction: wide coalesced reads report half -> 2 x FETCH_SIZE)."""
-    f = os.path.join(ROOT, "profiles", "r01_v4_conv3x3_64_64_1080p_pmc.txt")
+    f = os.path.join(ROOT, "profiles", "r01_v7_conv3x3_64_64_1080p_pmc.txt")
     if not os.path.exists(f):
         return None
     vals = {}

@@ -82,6 +82,9 @@ typedef struct {
 int tdvc_abi_version(void);
 /* Human-readable description of the last error on this thread (never NULL). */
 const char* tdvc_last_error(void);
+/* Name of the kernel the last tdvc_conv2d call on this thread dispatched to ("conv_mfma_v7", "conv_mfma<4,2,1>",
+ * ...; "" before the first call).  Diagnostic for profiles and benchmarks; never NULL. */
+const char* tdvc_last_conv_kernel(void);
 
 /* ---------------------------------------------------------------- conv transforms
  * Replaces every torch.nn.Conv2d / Conv3d(1,3,3) / Conv3d(3,1,1) / compressai

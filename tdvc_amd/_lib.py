@@ -46,6 +46,7 @@ _i, _f, _i64 = C.c_int, C.c_float, C.c_int64
 SIGNATURES = {
     "tdvc_abi_version": (_i, []),
     "tdvc_last_error": (C.c_char_p, []),
+    "tdvc_last_conv_kernel": (C.c_char_p, []),
     "tdvc_conv_plan": (_i, [_i, _i, _i, _i]),
     "tdvc_conv_packed_bytes": (_i64, [_i, _i, _i, _i]),
     "tdvc_pack_conv_weights": (_i, [_P, _i, _i, _i, _i, _i, _i, _P, _P, _i, _P]),

@@ -94,18 +94,19 @@ inline bool conv_is_simple(const ConvParams& p) {
   const bool shuf = p.out_mode == TDVC_OUT_SHUFFLE2;
   if (!(p.out_mode == TDVC_OUT_NHWC || shuf) || p.y.f32 || p.round16 || !p.bias) return false;
   if (p.gdn ? p.act != TDVC_ACT_NONE : !(p.act == TDVC_ACT_NONE || p.act == TDVC_ACT_RELU || p.act == TDVC_ACT_LRELU)) return false;
+  if (p.act == TDVC_ACT_LRELU && !(p.slope >= 0.f && p.slope <= 1.f)) return false;     // max(v, v*slope) form
   if (p.res.p && (p.res.f32 || p.res.C < p.y.C)) return false;
   if (p.res2.p && p.res2.C < p.y.C) return false;
   if (shuf && (((p.cout >> 2) % 64) != 0 || p.gdn)) return false;
   if (p.gdn && (p.aux.C < p.y.C || shuf)) return false;
   return true;
 }
-// slope that turns `v > 0 ? v : v * slope` into none / ReLU / LeakyReLU
+// slope that turns `max(v, v * slope)` into none / ReLU / LeakyReLU
 inline float conv_simple_slope(const ConvParams& p) {
   return p.act == TDVC_ACT_NONE ? 1.f : (p.act == TDVC_ACT_RELU ? 0.f : p.slope);
 }
 
-// Transposed "simple" epilogue shared by conv_mfma_v2/v3/v4: fp16 NHWC output (optionally through
+// Transposed "simple" epilogue shared by every conv kernel (v1 .. v7): fp16 NHWC output (optionally through
 // PixelShuffle(2)), bias, none / ReLU / LeakyReLU via a slope select, GDN / inverse GDN
 // (aux * rsqrt(v) | aux * sqrt(v)), up to two fp16 residuals.  One pass = one output row of 32 pixels x
 // 64 channels of this wave: bias + activation in the MFMA layout (4 consecutive channels per lane), fp16
@@ -116,7 +117,9 @@ inline float conv_simple_slope(const ConvParams& p) {
 // (1) pack: bias + activation in the MFMA layout -> fp16, 4 consecutive channels per (mt, g) slot.
 struct PackedRow { half4 v[8]; };           // [mt*4 + g] -> channels mt*32 + 8g + 4*(lane>>5) .. +3
 
-template <int NTX>
+// BIAS_IN_ACC: the caller initialised the accumulators with the bias (no add here, no re-zeroing).
+// The activation is max(v, v * slope): none (slope 1) / ReLU (0) / LeakyReLU (0 <= slope <= 1, conv_is_simple).
+template <int NTX, bool BIAS_IN_ACC = false>
 __device__ __forceinline__ void epilogue_pack(const ConvParams& p, f32x16 (&acc)[2][NTX], const float* bias64, int lane,
                                               PackedRow (&out)[NTX], bool zero_acc) {
   const int hh = lane >> 5;
@@ -127,13 +130,17 @@ __device__ __forceinline__ void epilogue_pack(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int cl = mt * 32 + 8 * g + 4 * hh;
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias64 + cl);
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (!BIAS_IN_ACC) b4 = *reinterpret_cast<const f32x4*>(bias64 + cl);
         half4 o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float v = acc[mt][nt][4 * g + i] + b4[i];
-          if (zero_acc) acc[mt][nt][4 * g + i] = 0.f;
-          v = v > 0.f ? v : v * p.slope;
+          float v = acc[mt][nt][4 * g + i];
+          if constexpr (!BIAS_IN_ACC) {
+            v += b4[i];
+            if (zero_acc) acc[mt][nt][4 * g + i] = 0.f;
+          }
+          v = __builtin_fmaxf(v, v * p.slope);
           o[i] = (half_t)v;
         }
         out[nt].v[mt * 4 + g] = o;
@@ -143,8 +150,10 @@ __device__ __forceinline__ void epilogue_pack(const ConvParams& p, f32x16 (&acc)
 // (2) store one output row (32 pixels x 64 channels of this wave) through the wave-private LDS region
 // `ew` (32 x 144 B): afterwards every lane owns 8 consecutive channels of a pixel, so GDN multiplicand,
 // residuals and the output move as full 128-byte lines; all loads are issued before any is consumed.
+// `full` (wave-uniform): the caller guarantees that the row and all 32 pixels are inside the image, so the
+// four stores are always issued (conv_mfma_v7 counts them in its s_waitcnt vmcnt bookkeeping).
 __device__ __forceinline__ void epilogue_store_row(const ConvParams& p, const PackedRow& row, unsigned char* ew, int n, int cbase,
-                                                   int oy, int ox_first, int lane) {
+                                                   int oy, int ox_first, int lane, bool full = false) {
   constexpr int EPS = 144;
   const int hh = lane >> 5, r = lane & 31;
   const int chunk = lane & 7, prow = lane >> 3;
@@ -174,7 +183,7 @@ __device__ __forceinline__ void epilogue_store_row(const ConvParams& p, const Pa
 #pragma unroll
     for (int k = 0; k < KB; ++k) {
       const int ox = ox_first + (k0 + k) * 8 + prow;
-      ok[k] = row_ok && ox < p.Wo;
+      ok[k] = full ? ch_ok : (row_ok && ox < p.Wo);
       opix[k] = ok[k] ? (long)(mul * oy + sub_y) * PW + (mul * ox + sub_x) : 0;
       apix[k] = ok[k] ? (long)oy * p.Wo + ox : 0;
     }
@@ -221,14 +230,14 @@ __device__ __forceinline__ void epilogue_store_row(const ConvParams& p, const Pa
 }
 
 // immediate form used by conv_mfma (v1), v2 and v3
-template <int NTX>
+template <int NTX, bool BIAS_IN_ACC = false>
 __device__ __forceinline__ void epilogue_simple_rows(const ConvParams& p, f32x16 (&acc)[2][NTX], const float* bias64,
                                                      unsigned char* ew, int n, int cbase, int oy_first, int ox_first,
-                                                     int lane, bool zero_acc) {
+                                                     int lane, bool zero_acc, bool full = false) {
   PackedRow rows[NTX];
-  epilogue_pack<NTX>(p, acc, bias64, lane, rows, zero_acc);
+  epilogue_pack<NTX, BIAS_IN_ACC>(p, acc, bias64, lane, rows, zero_acc);
 #pragma unroll
-  for (int nt = 0; nt < NTX; ++nt) epilogue_store_row(p, rows[nt], ew, n, cbase, oy_first + nt, ox_first, lane);
+  for (int nt = 0; nt < NTX; ++nt) epilogue_store_row(p, rows[nt], ew, n, cbase, oy_first + nt, ox_first, lane, full);
 }
 
 }  // namespace convk

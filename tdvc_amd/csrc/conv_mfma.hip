@@ -22,10 +22,10 @@ int launch_conv_v2(const ConvParams& p, int ntiles, int cout_blocks, int N, hipS
 bool conv_v2_eligible(const tdvc_conv_desc* d, int Ho, int Wo);
 int launch_conv_v3(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
 bool conv_v3_eligible(const tdvc_conv_desc* d, int Ho, int Wo);
-int launch_conv_v4(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
-bool conv_v4_eligible(const tdvc_conv_desc* d, int Ho, int Wo);
 int launch_conv_v5(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
 bool conv_v5_eligible(const tdvc_conv_desc* d, int Ho, int Wo);
+int launch_conv_v7(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
+bool conv_v7_eligible(const tdvc_conv_desc* d, const ConvParams& p, int Ho, int Wo);
 
 namespace {
 
@@ -245,6 +245,8 @@ extern "C" int tdvc_pack_conv_weights(const float* w, int cout, int cin_real, in
   return TDVC_OK;
 }
 
+static thread_local char g_last_kernel[48] = "";
+
 extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
   TDVC_CHECK(d, "tdvc_conv2d: null descriptor");
   TDVC_CHECK(fmap_ok16(d->x), "tdvc_conv2d: input must be an fp16 fmap with C,sp %% 8 == 0 and 16-byte aligned");
@@ -324,16 +326,19 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
     p.simple = 1;
     p.slope = convk::conv_simple_slope(p);
   }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  auto chose = [](const char* name) { snprintf(g_last_kernel, sizeof(g_last_kernel), "%s", name); };
   if (d->s2d) {
     TDVC_CHECK(conv_v3_eligible(d, Ho, Wo), "tdvc_conv2d: s2d conv not eligible for the stage-pipelined kernel");
-    return launch_conv_v3(p, tiles / 2, d->x.N, reinterpret_cast<hipStream_t>(stream));
+    chose("conv_mfma_v3(s2d)");
+    return launch_conv_v3(p, tiles / 2, d->x.N, st);
   }
-  if (conv_v5_eligible(d, Ho, Wo)) return launch_conv_v5(p, tiles / 2, d->x.N, reinterpret_cast<hipStream_t>(stream));
-  if (conv_v4_eligible(d, Ho, Wo)) return launch_conv_v4(p, tiles / 2, d->x.N, reinterpret_cast<hipStream_t>(stream));
-  if (conv_v3_eligible(d, Ho, Wo)) return launch_conv_v3(p, tiles / 2, d->x.N, reinterpret_cast<hipStream_t>(stream));
-  if (conv_v2_eligible(d, Ho, Wo)) return launch_conv_v2(p, 0, tiles / 2, d->x.N, reinterpret_cast<hipStream_t>(stream));
+  if (conv_v5_eligible(d, Ho, Wo)) { chose("conv_mfma_v5"); return launch_conv_v5(p, tiles / 2, d->x.N, st); }
+  if (conv_v7_eligible(d, p, Ho, Wo)) { chose("conv_mfma_v7"); return launch_conv_v7(p, tiles / 2, d->x.N, st); }
+  if (conv_v3_eligible(d, Ho, Wo)) { chose("conv_mfma_v3"); return launch_conv_v3(p, tiles / 2, d->x.N, st); }
+  if (conv_v2_eligible(d, Ho, Wo)) { chose("conv_mfma_v2"); return launch_conv_v2(p, 0, tiles / 2, d->x.N, st); }
   dim3 grid(tiles_x * tiles_y, tiles / mt, d->x.N);
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_mfma<%d,%d,%d>", ck8, mt, d->stride);
   const size_t lds_v1 = (p.simple && lds < 256 + 4 * 32 * 144) ? 256 + 4 * 32 * 144 : lds;
   switch (ck8) {
     case 1: return launch_m<1>(p, mt, d->stride, grid, lds_v1, st);
@@ -342,3 +347,5 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
     default: return launch_m<8>(p, mt, d->stride, grid, lds_v1, st);
   }
 }
+
+extern "C" const char* tdvc_last_conv_kernel(void) { return g_last_kernel; }

@@ -3,13 +3,13 @@
 // -input prologue), OffsetGen's 1x1 fusions.
 //
 // A 1x1 conv has no halo and no reuse between pixels: under the workgroup-tiled kernels a stage is one
-// tap = 8 MFMAs per wave between two barriers, i.e. barrier-bound (v4: 491 us for 256 -> 64 at 1080p =
-// 2.7 TB/s algorithmic).  Here every wave owns a PRIVATE 2x32-pixel tile in LDS (5 KB) next to the
+// tap = 8 MFMAs per wave between two barriers, i.e. barrier-bound (the shared-tile weight-stationary kernel
+// this replaced: 491 us for 256 -> 64 at 1080p = 2.7 TB/s algorithmic).  Here every wave owns a PRIVATE 2x32-pixel tile in LDS (5 KB) next to the
 // resident weights, so after the one-time weight load there is NO barrier: waves drift apart and one
 // wave's publish / epilogue / stores overlap its SIMD partner's MFMAs.  Measured 296 us = 4.5 TB/s
 // algorithmic (0.57 of HBM peak) for the same layer.
 // (The same scheme was tried for 3x3 windows — each wave loading its own 4-row halo — and measured 20 %
-// SLOWER than v4's shared tile, so v5 only takes 1x1.)
+// SLOWER than a shared tile, so v5 only takes 1x1; 3x3 is conv_mfma_v7.)
 #include <type_traits>
 
 #include "conv_common.h"

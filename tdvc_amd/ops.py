@@ -238,13 +238,7 @@ def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, 
         e0.record()
         L.check(L.lib().tdvc_conv2d(C.byref(d), _stream()), "conv2d")
         e1.record()
-        v2 = pc.ck == 32 and pc.stride == 1 and len(pc.taps) >= 2 and pc.cout >= 64 and (Ho * Wo >= 2048 or pc.s2d)
-        v3 = v2 and len(pc.taps) <= 9 and pc.kh <= 3 and pc.kw <= 3
-        v41 = pc.ck == 32 and pc.stride == 1 and len(pc.taps) == 1 and pc.cout >= 64 and Ho * Wo >= 8192
-        v4 = (v3 or v41) and not pc.s2d and Ho * Wo >= 8192 and 256 + 18 * 34 * 80 + ((x.C + 31) // 32) * len(pc.taps) * 4096 <= 150 * 1024
-        lds5 = 512 + ((x.C + 31) // 32) * len(pc.taps) * 4096 + 8 * max(4608, (1 + pc.kh) * (31 + pc.kw) * 80)
-        v5 = (v3 or v41) and not pc.s2d and Ho * Wo >= 8192 and lds5 <= 160 * 1024 and (pc.kh, pc.kw) == (1, 1)
-        PROFILE.append(dict(kernel="conv_mfma_v5" if v5 else "conv_mfma_v4" if v4 else "conv_mfma_v3(s2d)" if (v3 and pc.s2d) else "conv_mfma_v3" if v3 else "conv_mfma_v2" if v2 else f"conv_mfma<{pc.ck // 8},{1 if pc.cout <= 32 else 2},{pc.stride}>",
+        PROFILE.append(dict(kernel=L.lib().tdvc_last_conv_kernel().decode(),
                             e0=e0, e1=e1,
                             flops=2.0 * x.N * Ho * Wo * pc.cout * x.C * len(pc.taps),
                             flops_real=(x.N * Ho * Wo * pc.flops_per_px) if pc.s2d else 2.0 * x.N * Ho * Wo * pc.cout * pc.cin_real * len(pc.taps),

@@ -267,7 +267,7 @@ def test_conv_1x1_large_and_shuffle_large(report):
     r = rnd16(randn(1, 64, 192, 256, seed=71))
     ref = F.pixel_shuffle(F.conv2d(x, w, b, padding=1), 2) + r
     y = ops.conv(to_fm(x, ops), ops.pack_conv(w, b, stride=1, pad=1, shuffle=True), res=to_fm(r, ops))
-    assert_close(fm_to_cpu(y), ref, RT, AT, "subpel 64->64 large (v4)", report)
+    assert_close(fm_to_cpu(y), ref, RT, AT, "subpel 64->64 large (v7)", report)
     # 128 -> 512 shuffle at a v3 size, LeakyReLU(0.01)
     x = rnd16(randn(1, 128, 68, 120, seed=72))
     w = rnd16(randn(512, 128, 3, 3, seed=73) * 0.03)
@@ -292,3 +292,44 @@ def test_conv_stride2_s2d(H, W, report):
     y = ops.conv(to_fm(x, ops), pc, out_dtype=torch.float32)
     assert y.f32
     assert_close(fm_to_cpu(y), F.conv2d(x, w, b, stride=2, padding=1), 1e-4, 1e-4, f"s2d fp32 out {H}x{W}", report)
+
+
+# ---- 3x3 stride-1 convs at sizes that take the LDS-DMA double-buffered kernel (conv_mfma_v7) ---------
+V7_CASES = [
+    # name, N, cin, cout, H, W, act, n_res
+    ("v7_64_64_ragged", 1, 64, 64, 100, 150, "lrelu", 1),          # partial tiles on both edges
+    ("v7_64_64_exact", 1, 64, 64, 96, 128, "relu", 0),             # every tile full (counted-store path)
+    ("v7_32_64", 1, 32, 64, 96, 100, "none", 2),                   # one 32-channel chunk per tile
+    ("v7_64_216_batch2", 2, 64, 216, 90, 120, "lrelu", 0),         # Cout not a multiple of 64, batch in grid.z
+    ("v7_64_128_many_tiles", 1, 64, 128, 272, 480, "relu", 1),     # several tiles per persistent workgroup
+    ("v7_64_64_narrow", 1, 64, 64, 300, 40, "none", 0),            # 2 tile columns, 19 tile rows
+]
+
+
+@pytest.mark.parametrize("case", V7_CASES, ids=[c[0] for c in V7_CASES])
+def test_conv_v7(case, report):
+    ops = _ops()
+    name, N, cin, cout, H, W, act, n_res = case
+    x = rnd16(randn(N, cin, H, W, seed=81))
+    w = rnd16(randn(cout, cin, 3, 3, seed=82) * (1.0 / (cin * 9) ** 0.5))
+    b = randn(cout, seed=83) * 0.1
+    res = [rnd16(randn(N, cout, H, W, seed=84 + i)) for i in range(n_res)]
+    ref = F.conv2d(x, w, b, padding=1)
+    ref = {"lrelu": lambda t: F.leaky_relu(t, 0.1), "relu": F.relu, "none": lambda t: t}[act](ref)
+    for r in res:
+        ref = ref + r
+    pc = ops.pack_conv(w, b, stride=1, pad=1)
+    assert pc.ck == 32
+    kw = dict(act={"lrelu": ops.ACT_LRELU, "relu": ops.ACT_RELU, "none": ops.ACT_NONE}[act], slope=0.1)
+    if n_res > 0:
+        kw["res"] = to_fm(res[0], ops)
+    if n_res > 1:
+        kw["res2"] = to_fm(res[1], ops)
+    xf = to_fm(x, ops)
+    y = ops.conv(xf, pc, **kw)
+    assert_close(fm_to_cpu(y, cout), ref, RT, AT, f"conv {name}", report)
+    # the DMA / barrier protocol must give the same bits on every launch
+    first = y.t.clone()
+    for _ in range(5):
+        ops.conv(xf, pc, out=y, **kw)
+        assert torch.equal(y.t, first), f"{name}: launch-to-launch mismatch"

@@ -30,8 +30,9 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     a = ap.parse_args()
     for name, cin, cout, k, s, H, W in LAYERS:
-        x = ops.FM(torch.randn(1, H, W, cin, device="cuda").half())
-        w = torch.randn(cout, cin, k, k) * 0.05
+        zero = os.environ.get("TDVC_BENCH_ZERO") == "1"      # zero operands: separates power-limited clocks from stalls
+        x = ops.FM((torch.zeros if zero else torch.randn)(1, H, W, cin, device="cuda").half())
+        w = (torch.zeros if zero else torch.randn)(cout, cin, k, k) * 0.05
         pc = ops.pack_conv(w, torch.zeros(cout), stride=s, pad=k // 2)
         y = ops.conv(x, pc, act=ops.ACT_RELU)
         torch.cuda.synchronize()

@@ -18,14 +18,13 @@ x = ops.FM(torch.randn(1, H, W, cin, device="cuda").half())
 pc = ops.pack_conv(torch.randn(cout, cin, k, k) * 0.05, torch.zeros(cout), stride=1, pad=k // 2)
 y = ops.conv(x, pc, act=ops.ACT_RELU)
 torch.cuda.synchronize()
-for fn in (lib.tdvc_debug_set_stamp_buffer, lib.tdvc_debug_set_stamp_buffer_v3, lib.tdvc_debug_set_stamp_buffer_v4):
+for fn in (lib.tdvc_debug_set_stamp_buffer, lib.tdvc_debug_set_stamp_buffer_v3):
     fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
     fn(buf.data_ptr(), nb)
 ops.conv(x, pc, out=y, act=ops.ACT_RELU)
 torch.cuda.synchronize()
 lib.tdvc_debug_set_stamp_buffer(None, 0)
 lib.tdvc_debug_set_stamp_buffer_v3(None, 0)
-lib.tdvc_debug_set_stamp_buffer_v4(None, 0)
 s = buf.cpu().numpy().reshape(nb, 8)
 s = s[s[:, 0] > 0]
 n = int((s[0] > 0).sum())
