@@ -178,29 +178,29 @@ __device__ __forceinline__ void epilogue_store_row(const ConvParams& p, const Pa
 #pragma unroll
   for (int k0 = 0; k0 < 4; k0 += KB) {
     half8 r0[KB], r1[KB], r2[KB];
-    long opix[KB], apix[KB];
+    int opix[KB], apix[KB];               // pixel indices fit 32 bits (checked by the host); widened once per access
     bool ok[KB];
 #pragma unroll
     for (int k = 0; k < KB; ++k) {
       const int ox = ox_first + (k0 + k) * 8 + prow;
       ok[k] = full ? ch_ok : (row_ok && ox < p.Wo);
-      opix[k] = ok[k] ? (long)(mul * oy + sub_y) * PW + (mul * ox + sub_x) : 0;
-      apix[k] = ok[k] ? (long)oy * p.Wo + ox : 0;
+      opix[k] = ok[k] ? (mul * oy + sub_y) * PW + (mul * ox + sub_x) : 0;
+      apix[k] = ok[k] ? oy * p.Wo + ox : 0;
     }
     if (gdn) {
       const half_t* ab = reinterpret_cast<const half_t*>(p.aux.p) + (long)n * p.aux.sn + (ch_ok ? co : 0);
 #pragma unroll
-      for (int k = 0; k < KB; ++k) r0[k] = *reinterpret_cast<const half8*>(ab + apix[k] * p.aux.sp);
+      for (int k = 0; k < KB; ++k) r0[k] = *reinterpret_cast<const half8*>(ab + (long)apix[k] * p.aux.sp);
     }
     if (has1) {
       const half_t* rb = reinterpret_cast<const half_t*>(p.res.p) + (long)n * p.res.sn + pcc;
 #pragma unroll
-      for (int k = 0; k < KB; ++k) r1[k] = *reinterpret_cast<const half8*>(rb + opix[k] * p.res.sp);
+      for (int k = 0; k < KB; ++k) r1[k] = *reinterpret_cast<const half8*>(rb + (long)opix[k] * p.res.sp);
     }
     if (has2) {
       const half_t* rb = reinterpret_cast<const half_t*>(p.res2.p) + (long)n * p.res2.sn + pcc;
 #pragma unroll
-      for (int k = 0; k < KB; ++k) r2[k] = *reinterpret_cast<const half8*>(rb + opix[k] * p.res2.sp);
+      for (int k = 0; k < KB; ++k) r2[k] = *reinterpret_cast<const half8*>(rb + (long)opix[k] * p.res2.sp);
     }
 #pragma unroll
     for (int k = 0; k < KB; ++k) {
@@ -224,7 +224,7 @@ __device__ __forceinline__ void epilogue_store_row(const ConvParams& p, const Pa
 #pragma unroll
         for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
       }
-      if (ok[k]) *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.y.p) + (long)n * p.y.sn + opix[k] * p.y.sp + pc) = h;
+      if (ok[k]) *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.y.p) + (long)n * p.y.sn + (long)opix[k] * p.y.sp + pc) = h;
     }
   }
 }

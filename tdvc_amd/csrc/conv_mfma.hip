@@ -270,6 +270,7 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
     Wo = d->x.W / 2;
   }
   TDVC_CHECK(Ho > 0 && Wo > 0, "tdvc_conv2d: empty output");
+  TDVC_CHECK((long)Ho * Wo * 4 < 2147483647L && (long)d->x.H * d->x.W < 2147483647L, "tdvc_conv2d: image too large (pixel indices are 32-bit)");
   const int lds = lds_bytes(d->ck, d->kh, d->kw, d->stride);
   TDVC_CHECK(lds <= 64 * 1024, "tdvc_conv2d: LDS plan %d bytes too large (use tdvc_conv_plan)", lds);
 
