@@ -202,6 +202,10 @@ __global__ __launch_bounds__(NTHR7, 1) void conv_mfma_v7_kernel(const ConvParams
 #pragma unroll
         for (int nt = 0; nt < NT7; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i & 1][mt], fb[i & 1][nt], acc[mt][nt], 0, 0, 0);
+      // pin the software pipeline: all four fragment reads of half tap i+1 are issued BEFORE the four MFMAs
+      // of half tap i (left alone, hipcc sinks them behind the second MFMA and the next group stalls on them)
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       if (i < DMA7 && have_next) issue_one(i, nbuf);
     }
     if (e.prio) __builtin_amdgcn_s_setprio(0);

@@ -30,6 +30,4 @@ s = s[s[:, 0, 0] > 0]
 rel = s[:, :, :6] - s[:, :, :1].min(axis=1, keepdims=True)
 print("blocks", len(s))
 for w in range(8):
-    print("wave", w, "stage-5 stamps (rel):", np.median(rel[:, w], axis=0).astype(int).tolist(),
-          " entry->stage5:", int(np.median(s[:, w, 0] - s[:, w, 6])), " entry->exit:", int(np.median(s[:, w, 7] - s[:, w, 6])))
-print("kernel span (cycles, min entry -> max exit):", int(s[:, :, 7].max() - s[:, :, 6].min()))
+    print("wave", w, "stamps of the instrumented stage, relative to the workgroup's first:", np.median(rel[:, w], axis=0).astype(int).tolist())
