@@ -180,8 +180,10 @@ int tdvc_resize_bilinear(const tdvc_fmap* x, const tdvc_fmap* y, const float* ch
 
 /* ---------------------------------------------------------------- in-loop filter matching
  * FeatureFix.forward, main/model/pnet.py:219-255. */
-/* scale x scale average pooling (floor), fp16 fmap -> fp32 [N][hp][wp][C] (nn.AvgPool2d, :224-225) */
-int tdvc_avgpool_k(const tdvc_fmap* x, int scale, float* pooled, int hp, int wp, void* stream);
+/* scale x scale average pooling (floor), fp16 fmap -> fp32 [N][hp][wp][C] (nn.AvgPool2d, :224-225).
+ * Two order-fixed stages through `work` (>= tdvc_avgpool_k_work_floats(..) floats of device memory). */
+int64_t tdvc_avgpool_k_work_floats(int N, int hp, int wp, int C, int scale);
+int tdvc_avgpool_k(const tdvc_fmap* x, int scale, float* pooled, int hp, int wp, float* work, int64_t work_floats, void* stream);
 /* 3x3 / stride-3 / pad-3 patches of both pooled maps, L2-normalise, cosine similarity, first
  * -index argmax over reference patches -> idx[N][L] int32, L = ((hp+3)/3+1)*((wp+3)/3+1)
  * (F.unfold + normalize + bmm + max, :230-236). */

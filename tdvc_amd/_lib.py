@@ -65,7 +65,8 @@ SIGNATURES = {
     "tdvc_avgpool2": (_i, [_FM, _FM, _P]),
     "tdvc_spynet_level_input": (_i, [_FM, _FM, _FM, _FM, _FM, _P]),
     "tdvc_resize_bilinear": (_i, [_FM, _FM, _P, _P]),
-    "tdvc_avgpool_k": (_i, [_FM, _i, _P, _i, _i, _P]),
+    "tdvc_avgpool_k_work_floats": (_i64, [_i, _i, _i, _i, _i]),
+    "tdvc_avgpool_k": (_i, [_FM, _i, _P, _i, _i, _P, _i64, _P]),
     "tdvc_patch_match": (_i, [_P, _P, _i, _i, _i, _i, _P, _P]),
     "tdvc_match_gather": (_i, [_FM, _FM, _P, _i, _i, _i, _FM, _P]),
     "tdvc_eb_forward": (_i, [_FM, _P, _FM, _FM, _P, _P, _i, _P]),

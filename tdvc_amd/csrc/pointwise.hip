@@ -321,24 +321,40 @@ __global__ void resize_bilinear_kernel(FMap x, FMap y, const float* chscale) {
 }
 
 // ------------------------------------------------------------------ in-loop filter matching
-// one block per pooled cell: mean over scale x scale pixels of every channel
-__global__ __launch_bounds__(256) void avgpool_k_kernel(FMap x, int scale, float* pooled, int hp, int wp) {
+// Stage 1: one block per (pooled cell, strip of POOL_ROWS rows): channel sums of the strip -> work[cell][strip][C].
+// Stage 2: one thread per (cell, channel): strips summed in order, / area.  (The FeatureFix pooling at 1080p is
+// 136 x 136 pixels per cell and only 8 x 14 cells: one block per cell left 144 of 256 CUs idle and ran 0.8 TB/s.)
+constexpr int POOL_ROWS = 8;
+__global__ __launch_bounds__(256) void avgpool_k_strip_kernel(FMap x, int scale, float* work, int wp, int nsplit) {
   __shared__ float red[256][9];
   const int chunks = x.C / 8;
   const int lanes = 256 / chunks;
   const int tid = threadIdx.x;
   const int ck = tid % chunks, pl = tid / chunks;
-  const int cell = blockIdx.x, n = blockIdx.y;
+  const int cell = blockIdx.x / nsplit, strip = blockIdx.x - cell * nsplit, n = blockIdx.y;
   const int py = cell / wp, px = cell % wp;
+  const int r0 = strip * POOL_ROWS, rows = min(POOL_ROWS, scale - r0);
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  const int area = scale * scale;
+  const int area = rows * scale;
   if (pl < lanes) {
-    for (int k = pl; k < area; k += lanes) {
-      const int yy = py * scale + k / scale, xx = px * scale + k % scale;
+    int k = pl;                          // four independent 16-byte loads in flight per thread
+    for (; k + 3 * lanes < area; k += 4 * lanes) {
+      float v[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kk = k + u * lanes;
+        load8(x, n, (long)(py * scale + r0 + kk / scale) * x.W + (px * scale + kk % scale), ck * 8, v[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += v[u][j];
+    }
+    for (; k < area; k += lanes) {
       float v[8];
-      load8(x, n, (long)yy * x.W + xx, ck * 8, v);
+      load8(x, n, (long)(py * scale + r0 + k / scale) * x.W + (px * scale + k % scale), ck * 8, v);
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] += v[j];
     }
@@ -350,8 +366,18 @@ __global__ __launch_bounds__(256) void avgpool_k_kernel(FMap x, int scale, float
     const int cc = tid / 8, j = tid % 8;
     float s = 0.f;
     for (int l = 0; l < lanes; ++l) s += red[l * chunks + cc][j];
-    pooled[(((long)n * hp + py) * wp + px) * x.C + tid] = s / (float)area;
+    work[(((long)n * gridDim.x) + blockIdx.x) * x.C + tid] = s;
   }
+}
+
+__global__ void avgpool_k_final_kernel(const float* work, float* pooled, long total, int C_, int nsplit, float area) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long cell = i / C_;
+  const int c = (int)(i - cell * C_);
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += work[(cell * nsplit + k) * C_ + c];
+  pooled[i] = s / area;
 }
 
 __device__ __forceinline__ float block_sum(float v, float* sh) {
@@ -673,10 +699,18 @@ extern "C" int tdvc_resize_bilinear(const tdvc_fmap* x, const tdvc_fmap* y, cons
   return tdvc_launch_status("tdvc_resize_bilinear");
 }
 
-extern "C" int tdvc_avgpool_k(const tdvc_fmap* x, int scale, float* pooled, int hp, int wp, void* stream) {
-  TDVC_CHECK(x && pooled && fmap_ok16(*x) && x->C <= 256 && scale >= 1 && hp == x->H / scale && wp == x->W / scale && hp >= 1 && wp >= 1,
+extern "C" int64_t tdvc_avgpool_k_work_floats(int N, int hp, int wp, int C_, int scale) {
+  return (int64_t)N * hp * wp * ((scale + POOL_ROWS - 1) / POOL_ROWS) * C_;
+}
+
+extern "C" int tdvc_avgpool_k(const tdvc_fmap* x, int scale, float* pooled, int hp, int wp, float* work, int64_t work_floats, void* stream) {
+  TDVC_CHECK(x && pooled && work && fmap_ok16(*x) && x->C <= 256 && scale >= 1 && hp == x->H / scale && wp == x->W / scale && hp >= 1 && wp >= 1,
              "tdvc_avgpool_k: bad arguments");
-  hipLaunchKernelGGL(avgpool_k_kernel, dim3(hp * wp, x->N), dim3(256), 0, ST(stream), to_dev(*x), scale, pooled, hp, wp);
+  const int nsplit = (scale + POOL_ROWS - 1) / POOL_ROWS;
+  TDVC_CHECK(work_floats >= tdvc_avgpool_k_work_floats(x->N, hp, wp, x->C, scale), "tdvc_avgpool_k: workspace too small (tdvc_avgpool_k_work_floats)");
+  hipLaunchKernelGGL(avgpool_k_strip_kernel, dim3(hp * wp * nsplit, x->N), dim3(256), 0, ST(stream), to_dev(*x), scale, work, wp, nsplit);
+  const long total = (long)x->N * hp * wp * x->C;
+  hipLaunchKernelGGL(avgpool_k_final_kernel, grid1d(total), dim3(256), 0, ST(stream), work, pooled, total, x->C, nsplit, (float)scale * (float)scale);
   return tdvc_launch_status("tdvc_avgpool_k");
 }
 

@@ -338,8 +338,10 @@ def resize_bilinear(x: FM, H: int, W: int, chscale: torch.Tensor | None = None) 
 def avgpool_k(x: FM, scale: int) -> torch.Tensor:
     hp, wp = x.H // scale, x.W // scale
     pooled = torch.empty((x.N, hp, wp, x.C), dtype=torch.float32, device=x.t.device)
+    nwork = L.lib().tdvc_avgpool_k_work_floats(x.N, hp, wp, x.C, scale)
+    work = torch.empty((nwork,), dtype=torch.float32, device=x.t.device)
     dx = x.desc()
-    L.check(L.lib().tdvc_avgpool_k(C.byref(dx), scale, pooled.data_ptr(), hp, wp, _stream()), "avgpool_k")
+    L.check(L.lib().tdvc_avgpool_k(C.byref(dx), scale, pooled.data_ptr(), hp, wp, work.data_ptr(), nwork, _stream()), "avgpool_k")
     return pooled
 
 
