@@ -10,6 +10,7 @@ struct ConvParams {
   FMap y; int Ho, Wo; int cout;
   FMap aux; FMap res; FMap res2;
   int ntaps, kh, kw, pad;
+  int in_stride;        // input pixels per output pixel (conv_mfma_v5: 1x1 stride-2 skip convs; 1 elsewhere)
   int nchunks, steps;   // steps per chunk
   int square, gdn, act; float slope; int round16, out_mode;
   int tiles_x;

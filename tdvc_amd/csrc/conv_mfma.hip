@@ -272,7 +272,6 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
   TDVC_CHECK(Ho > 0 && Wo > 0, "tdvc_conv2d: empty output");
   TDVC_CHECK((long)Ho * Wo * 4 < 2147483647L && (long)d->x.H * d->x.W < 2147483647L, "tdvc_conv2d: image too large (pixel indices are 32-bit)");
   const int lds = lds_bytes(d->ck, d->kh, d->kw, d->stride);
-  TDVC_CHECK(lds <= 64 * 1024, "tdvc_conv2d: LDS plan %d bytes too large (use tdvc_conv_plan)", lds);
 
   const int shuf = d->out_mode == TDVC_OUT_SHUFFLE2;
   if (d->out_mode == TDVC_OUT_NCHW_F32) {
@@ -311,6 +310,7 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
   p.res = d->res.p ? to_dev(d->res) : null_fmap();
   p.res2 = d->res2.p ? to_dev(d->res2) : null_fmap();
   p.ntaps = d->ntaps; p.kh = d->kh; p.kw = d->kw; p.pad = d->pad;
+  p.in_stride = d->stride;
   const int ck8 = d->ck / 8;
   p.s2d = d->s2d; p.Corig = d->x.C;
   p.nchunks = d->s2d ? (4 * d->x.C) / d->ck : (d->x.C + d->ck - 1) / d->ck;
@@ -338,6 +338,7 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
   if (conv_v7_eligible(d, p, Ho, Wo)) { chose("conv_mfma_v7"); return launch_conv_v7(p, tiles / 2, d->x.N, st); }
   if (conv_v3_eligible(d, Ho, Wo)) { chose("conv_mfma_v3"); return launch_conv_v3(p, tiles / 2, d->x.N, st); }
   if (conv_v2_eligible(d, Ho, Wo)) { chose("conv_mfma_v2"); return launch_conv_v2(p, 0, tiles / 2, d->x.N, st); }
+  TDVC_CHECK(lds <= 64 * 1024, "tdvc_conv2d: LDS plan %d bytes too large for the direct kernel (use tdvc_conv_plan)", lds);
   dim3 grid(tiles_x * tiles_y, tiles / mt, d->x.N);
   snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_mfma<%d,%d,%d>", ck8, mt, d->stride);
   const size_t lds_v1 = (p.simple && lds < 256 + 4 * 32 * 144) ? 256 + 4 * 32 * 144 : lds;

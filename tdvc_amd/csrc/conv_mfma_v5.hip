@@ -89,7 +89,7 @@ __global__ __launch_bounds__(NTHR5, 1) void conv_mfma_v5_kernel(const ConvParams
     unsigned m = 0;
 #pragma unroll
     for (int j = 0; j < TL; ++j) {
-      const int iy = iy0 + it_rr[j], ix = ix0 + it_c[j];
+      const int iy = (iy0 + it_rr[j]) * p.in_stride, ix = (ix0 + it_c[j]) * p.in_stride;    // in_stride > 1 only for 1x1, pad 0
       const bool ok = cok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
       const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
       const half_t* src = xn + ((long)iyc * p.W + ixc) * p.x_sp + cgc;
@@ -215,8 +215,10 @@ bool conv_v5_eligible(const tdvc_conv_desc* d, int Ho, int Wo) {
   if (off) return false;
   const int nchunks = (d->x.C + CK5 - 1) / CK5;
   const int tl = v5_tl(d->kh, d->kw);
-  return d->ck == 32 && d->stride == 1 && d->ntaps >= 1 && d->ntaps <= 9 && d->kh <= 3 && d->kw <= 3 && d->cout >= 64 &&
-         d->x.C >= 32 && !d->s2d && (long)Ho * Wo >= 8192 && tl == 4 &&
+  const bool stride_ok = d->stride == 1 || (d->stride == 2 && d->kh == 1 && d->kw == 1 && d->pad == 0);   // ResidualBlockWithStride skips
+  return d->ck == 32 && stride_ok && d->ntaps >= 1 && d->ntaps <= 9 && d->kh <= 3 && d->kw <= 3 && d->cout >= 64 &&
+         d->x.C >= 32 && !d->s2d && ((long)Ho * Wo >= 8192 || d->stride == 2) && tl == 4 &&     // stride 2: the only ck = 32 kernel that takes it
+
          v5_lds_bytes(d->kh, d->kw, d->ntaps, nchunks) <= 160 * 1024;
 }
 

@@ -172,8 +172,8 @@ def pack_conv(weight: torch.Tensor, bias: torch.Tensor | None, stride=1, pad=0, 
         taps = [(dy, dx) for dy in range(kh) for dx in range(kw)]
     lib = L.lib()
     if ck is None:
-        if stride == 1 and cin >= 32 and cout >= 64:
-            ck = 32          # the persistent pipelined kernel (conv_mfma_v2) streams 32-channel chunks
+        if (stride == 1 or (stride == 2 and kh == 1 and kw == 1 and pad == 0)) and cin >= 32 and cout >= 64:
+            ck = 32          # the weight-stationary / pipelined kernels stream 32-channel chunks
         else:
             ck = lib.tdvc_conv_plan(cin, kh, kw, stride)
             L.check(0 if ck > 0 else ck, "conv_plan")
@@ -239,6 +239,7 @@ def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, 
         L.check(L.lib().tdvc_conv2d(C.byref(d), _stream()), "conv2d")
         e1.record()
         PROFILE.append(dict(kernel=L.lib().tdvc_last_conv_kernel().decode(),
+                            shape=f"{pc.kh}x{pc.kw} s{pc.stride} {x.C}->{pc.cout} @{x.H}x{x.W}" + (" f32out" if out_dtype != torch.float16 else "") + (" nchw" if nchw_out is not None else ""),
                             e0=e0, e1=e1,
                             flops=2.0 * x.N * Ho * Wo * pc.cout * x.C * len(pc.taps),
                             flops_real=(x.N * Ho * Wo * pc.flops_per_px) if pc.s2d else 2.0 * x.N * Ho * Wo * pc.cout * pc.cin_real * len(pc.taps),

@@ -333,3 +333,16 @@ def test_conv_v7(case, report):
     for _ in range(5):
         ops.conv(xf, pc, out=y, **kw)
         assert torch.equal(y.t, first), f"{name}: launch-to-launch mismatch"
+
+
+@pytest.mark.parametrize("cin,cout,H,W", [(64, 128, 128, 160), (128, 128, 101, 131)])
+def test_conv_1x1_stride2_large(cin, cout, H, W, report):
+    """ResidualBlockWithStride skip conv (1x1, stride 2) at a size that takes the weight-stationary 1x1 kernel"""
+    ops = _ops()
+    x = rnd16(randn(2, cin, H, W, seed=91))
+    w = rnd16(randn(cout, cin, 1, 1, seed=92) * 0.08)
+    b = randn(cout, seed=93) * 0.1
+    pc = ops.pack_conv(w, b, stride=2, pad=0)
+    assert pc.ck == 32
+    y = ops.conv(to_fm(x, ops), pc)
+    assert_close(fm_to_cpu(y), F.conv2d(x, w, b, stride=2), RT, AT, f"1x1 s2 {cin}->{cout} {H}x{W}", report)
