@@ -206,14 +206,10 @@ __device__ __forceinline__ void epilogue_store_row(const ConvParams& p, const Pa
 #pragma unroll
     for (int k = 0; k < KB; ++k) {
       half8 h = *reinterpret_cast<const half8*>(ew + ((k0 + k) * 8 + prow) * EPS + chunk * 16);
-      if (gdn || has1 || has2) {
+      if (gdn) {                          // coder path: fp32 arithmetic, one rounding at the end
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
-        if (gdn) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = (float)r0[k][j] * (p.gdn == TDVC_GDN_FWD ? rsqrtf(v[j]) : sqrtf(v[j]));
-        }
+        for (int j = 0; j < 8; ++j) v[j] = (float)r0[k][j] * (p.gdn == TDVC_GDN_FWD ? rsqrtf((float)h[j]) : sqrtf((float)h[j]));
         if (has1) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += (float)r1[k][j];
@@ -224,6 +220,12 @@ __device__ __forceinline__ void epilogue_store_row(const ConvParams& p, const Pa
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
+      } else {
+        // residuals as packed fp16 adds (4 instructions per 8 channels instead of ~28 through fp32), which is
+        // also what the reference computes under AMP: the conv result is an fp16 tensor, `out + x` an fp16 add
+        // (utils.py:52-56), and an outer skip is a second fp16 add
+        if (has1) h = h + r1[k];
+        if (has2) h = h + r2[k];
       }
       if (ok[k]) *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.y.p) + (long)n * p.y.sn + (long)opix[k] * p.y.sp + pc) = h;
     }
