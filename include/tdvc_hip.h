@@ -262,6 +262,34 @@ int tdvc_ar_indexes(const tdvc_fmap* gp, const int32_t* pos, int npos, const flo
 /* q[n][h][w][c] = round(z - median[c]) as int32 in the fmap's own order (factorised-prior symbols). */
 int tdvc_round_symbols(const tdvc_fmap* z, const float* median, int32_t* out, void* stream);
 
+/* ---------------------------------------------------------------- conv backward (training path)
+ * torch.autograd's conv backward on the reference path (tools/train.py:142-159 drives loss.backward()):
+ * dX runs on tdvc_conv2d with weights re-packed by tdvc_pack_conv_weights_indexed (tdvc_amd/convpack.py builds
+ * the index tables); dW is tdvc_conv_wgrad; db is tdvc_channel_sum. */
+/* Device-side packing: element (row r, channel c, tap t) of the packed conv = w[row_off[r] + chan_off[c] + tap_off[t]],
+ * zero when row_off[r] < 0, chan_off[c] < 0 or tap_mask[t] & (row_mask[r] | chan_mask[c]).  All pointers are device
+ * memory; `dst` has tdvc_conv_packed_bytes(cout, cin, ntaps, ck) bytes. */
+int tdvc_pack_conv_weights_indexed(const float* w, const int32_t* row_off, const int32_t* chan_off, const int32_t* tap_off,
+                                   const uint8_t* row_mask, const uint8_t* chan_mask, const uint8_t* tap_mask,
+                                   int cout, int cin, int ntaps, int ck, void* dst, void* stream);
+/* dW[row_off[co] + chan_off[ci] + tap_off[t]] += scale * sum_{n,oy,ox} g[n,oy,ox,co] * x[n, oy*stride + dy_t - pad, ox*stride + dx_t - pad, ci]
+ * for the forward conv y = conv(x, W); g = dL/dy (fp16 fmap, >= cout channels; for a sub-pixel conv the un-shuffled
+ * gradient in packed-row order), dW the fp32 parameter gradient.  row_off[cout] / chan_off[x.C] / tap_off[ntaps] are the
+ * layer's forward packing tables (device int32; negative row / channel entries are skipped).  Two order-fixed stages
+ * through `work` (>= tdvc_conv_wgrad_work_floats(cout, x.C, ntaps, N, Ho, Wo) floats of device memory). */
+int64_t tdvc_conv_wgrad_work_floats(int cout, int cin, int ntaps, int N, int Ho, int Wo);
+int tdvc_conv_wgrad(const tdvc_fmap* g, const tdvc_fmap* x, int cout, int kh, int kw, int stride, int pad,
+                    int ntaps, const int8_t* tap_dy, const int8_t* tap_dx, const int32_t* row_off, const int32_t* chan_off,
+                    const int32_t* tap_off, float scale, float* dw, float* work, int64_t work_floats, void* stream);
+
+/* out = g * act'(z), ReLU / LeakyReLU, the sign of z taken from the stored output (y - res); out may alias g. */
+int tdvc_act_backward(const tdvc_fmap* g, const tdvc_fmap* y, const tdvc_fmap* res, int act, float slope, const tdvc_fmap* out, void* stream);
+/* out[n][Y][X][(i*2+j)*C + c] = y[n][2Y+i][2X+j][c] (adjoint of the PixelShuffle(2) store, packed-row order). */
+int tdvc_pixel_unshuffle(const tdvc_fmap* y, const tdvc_fmap* out, void* stream);
+/* db[dst_index[c] or c] += scale * sum_{n,h,w} g[n,h,w,c] for c < nvalid (two order-fixed stages through `work`). */
+int64_t tdvc_bias_grad_work_floats(int N, int C);
+int tdvc_bias_grad(const tdvc_fmap* g, int nvalid, const int32_t* dst_index, float scale, float* db, float* work, int64_t work_floats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,13 @@ SIGNATURES = {
     "tdvc_conv_packed_bytes": (_i64, [_i, _i, _i, _i]),
     "tdvc_pack_conv_weights": (_i, [_P, _i, _i, _i, _i, _i, _i, _P, _P, _i, _P]),
     "tdvc_conv2d": (_i, [C.POINTER(ConvDesc), _P]),
+    "tdvc_pack_conv_weights_indexed": (_i, [_P] * 7 + [_i] * 4 + [_P, _P]),
+    "tdvc_act_backward": (_i, [_FM, _FM, _FM, _i, _f, _FM, _P]),
+    "tdvc_pixel_unshuffle": (_i, [_FM, _FM, _P]),
+    "tdvc_bias_grad_work_floats": (_i64, [_i, _i]),
+    "tdvc_bias_grad": (_i, [_FM, _i, _P, _f, _P, _P, _i64, _P]),
+    "tdvc_conv_wgrad_work_floats": (_i64, [_i] * 6),
+    "tdvc_conv_wgrad": (_i, [_FM, _FM] + [_i] * 6 + [_P] * 5 + [_f, _P, _P, _i64, _P]),
     "tdvc_dcn_fused": (_i, [C.POINTER(DcnDesc), _P]),
     "tdvc_dcn_v2_forward_f32": (_i, [_P] * 6 + [_i] * 14 + [_P]),
     "tdvc_dcn_v2_backward_f32": (_i, [_P] * 12 + [_i] * 14 + [_P]),

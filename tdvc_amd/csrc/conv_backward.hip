@@ -1,0 +1,280 @@
+// Conv backward building blocks (training path, SURVEY §8a "Training multiplies a2-a15 by ~3").
+//
+//   * tdvc_pack_conv_weights_indexed: fp32 master weights (the nn.Parameter, on the device) -> the fp16 MFMA
+//     fragment order of the conv kernels, through three small index tables (row / channel / tap).  The same
+//     kernel produces the forward packing (with PixelShuffle row permutation, concatenation channel
+//     permutation, the space-to-depth form of stride-2 convs) and the DATA-GRADIENT packing (rows and
+//     channels swapped, taps mirrored), so dgrad runs on the forward conv kernels: dX = conv(dY, W^T flipped).
+//   * tdvc_conv_wgrad: dW[co][ci][dy][dx] += sum_{n,oy,ox} dY[n,oy,ox,co] * X[n, oy*s+dy-pad, ox*s+dx-pad, ci].
+//     A contraction over PIXELS, while both tensors are stored channel-innermost: the K index of the MFMA
+//     operands is the slow index in memory.  Tiles are staged pixel-major in LDS exactly like the forward
+//     tiles and read with gfx950's transposing LDS read (ds_read_b64_tr_b16: a 4 x 16 block delivered
+//     column-major), two reads per 32x16 operand fragment.  One workgroup owns a (64 co x 32 ci x <= 12 taps)
+//     block of dW in registers and walks a strided set of 8x32-pixel blocks; partial results go to a
+//     workspace and are reduced in a fixed order (bitwise reproducible, no float atomics).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ packing
+__global__ void pack_indexed_kernel(const float* __restrict__ w, const int* __restrict__ row_off, const int* __restrict__ chan_off,
+                                    const int* __restrict__ tap_off, const unsigned char* __restrict__ row_mask,
+                                    const unsigned char* __restrict__ chan_mask, const unsigned char* __restrict__ tap_mask,
+                                    int cout, int cin, int ntaps, int ck,
+                                    int nchunks, int steps, long total, half_t* __restrict__ out) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;          // one thread per 8 packed halves
+  if (e >= total) return;
+  const int lane = (int)(e & 63);
+  long q = e >> 6;
+  const int s = (int)(q % steps); q /= steps;
+  const int ch = (int)(q % nchunks);
+  const int t = (int)(q / nchunks);
+  const int ck8 = ck >> 3;
+  const int r = lane & 31, h = lane >> 5;
+  const int co = t * 32 + r, kc = 2 * s + h;
+  half8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (half_t)0.f;
+  if (kc < ntaps * ck8 && co < cout) {
+    const int tap = kc / ck8, c8 = kc - tap * ck8;
+    const int ro = row_off[co], to = tap_off[tap];               // tap offsets may be negative (relative forms)
+    const unsigned tm = tap_mask[tap];
+    if (ro >= 0 && (tm & row_mask[co]) == 0u) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ci = ch * ck + c8 * 8 + j;
+        if (ci < cin) {
+          const int cof = chan_off[ci];
+          if (cof >= 0 && (tm & chan_mask[ci]) == 0u) o[j] = (half_t)w[(long)ro + cof + to];
+        }
+      }
+    }
+  }
+  *reinterpret_cast<half8*>(out + e * 8) = o;
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad
+constexpr int WG_TH = 8, WG_TW = 32;            // output pixels per block
+constexpr int WG_CO = 64, WG_CI = 32;           // dW block per workgroup
+constexpr int WG_MAXT = 12;                     // taps per workgroup (3 per wave)
+constexpr int PSG = WG_CO * 2 + 16;             // LDS bytes per pixel of the dY tile (144)
+constexpr int PSX = WG_CI * 2 + 16;             // ... of the X tile (80)
+
+struct WgradParams {
+  FMap g, x;
+  int Ho, Wo, stride, pad;
+  int ntaps_all, tap0, ntaps;                   // this launch's tap group [tap0, tap0 + ntaps) of the layer's tap list
+  int8_t tap_dy[TDVC_MAX_TAPS], tap_dx[TDVC_MAX_TAPS];
+  int co_tiles, ci_tiles;
+  int blocks_x, blocks_y, nblocks;              // pixel blocks per image, total over the batch
+  int tih, tiw;                                 // X tile extent in pixels
+  float* work;                                  // [P][co_tiles*64][ci_tiles*32][ntaps_all]
+};
+
+typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
+
+__device__ __forceinline__ half4 tr_read(const unsigned char* p) {
+  const short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(p));
+  return __builtin_bit_cast(half4, v);
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* gt = smem;                                         // dY tile: WG_TH*WG_TW pixels x PSG
+  unsigned char* xt = smem + WG_TH * WG_TW * PSG;                   // X tile: tih*tiw pixels x PSX
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cit = blockIdx.x % p.ci_tiles, cot = blockIdx.x / p.ci_tiles;
+  const int worker = blockIdx.y, nworkers = gridDim.y;
+  const int co0 = cot * WG_CO, ci0 = cit * WG_CI;
+
+  // taps of this wave: wave, wave + 4, wave + 8 (inside the launch's group)
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][m][i] = 0.f;
+
+  // transposing-read lane geometry: 16-lane group gq, lane i = 4q + pp supplies (row q, columns 4pp .. 4pp+3)
+  const int gq = lane >> 4, li = lane & 15, rq = li >> 2, cp = li & 3;
+  const int khalf = gq >> 1;                                        // k = 8*khalf + {0..7}
+  const int colbase = 16 * (gq & 1) + 4 * cp;                       // column (channel) this lane ADDRESSES
+
+  for (int blk = worker; blk < p.nblocks; blk += nworkers) {
+    const int n = blk / (p.blocks_x * p.blocks_y);
+    const int rem = blk - n * (p.blocks_x * p.blocks_y);
+    const int by = rem / p.blocks_x, bx = rem - by * p.blocks_x;
+    const int oy0 = by * WG_TH, ox0 = bx * WG_TW;
+    const int iy0 = oy0 * p.stride - p.pad, ix0 = ox0 * p.stride - p.pad;
+    __syncthreads();                                                // previous block's reads are done
+    // ---- stage dY tile (zero outside the output / beyond the channel count)
+    for (int it = tid; it < WG_TH * WG_TW * (WG_CO / 8); it += 256) {
+      const int c8 = it & 7, px = it >> 3;
+      const int yy = px / WG_TW, xx = px - yy * WG_TW;
+      const int oy = oy0 + yy, ox = ox0 + xx, c = co0 + c8 * 8;
+      half8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
+      if (oy < p.Ho && ox < p.Wo && c < p.g.C)
+        v = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(p.g.p) + (long)n * p.g.sn + ((long)oy * p.Wo + ox) * p.g.sp + c);
+      *reinterpret_cast<half8*>(gt + px * PSG + c8 * 16) = v;
+    }
+    // ---- stage X tile
+    for (int it = tid; it < p.tih * p.tiw * (WG_CI / 8); it += 256) {
+      const int c8 = it & 3, px = it >> 2;
+      const int yy = px / p.tiw, xx = px - yy * p.tiw;
+      const int iy = iy0 + yy, ix = ix0 + xx, c = ci0 + c8 * 8;
+      half8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
+      if (iy >= 0 && iy < p.x.H && ix >= 0 && ix < p.x.W && c < p.x.C)
+        v = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(p.x.p) + (long)n * p.x.sn + ((long)iy * p.x.W + ix) * p.x.sp + c);
+      *reinterpret_cast<half8*>(xt + px * PSX + c8 * 16) = v;
+    }
+    __syncthreads();
+    // ---- contraction: k-steps of 16 consecutive output pixels of one row
+    for (int yy = 0; yy < WG_TH; ++yy) {
+#pragma unroll
+      for (int kh = 0; kh < WG_TW / 16; ++kh) {
+        const int pk = yy * WG_TW + kh * 16 + 8 * khalf + rq;        // dY pixel of the row this lane addresses (j = 0..3)
+        half8 a[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const unsigned char* ap = gt + pk * PSG + (m * 32 + colbase) * 2;
+          const half4 lo = tr_read(ap), hi = tr_read(ap + 4 * PSG);
+          a[m] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int ai = 0; ai < 3; ++ai) {
+          const int t = wave + 4 * ai;
+          if (t < p.ntaps) {                                         // wave-uniform
+            const int dy = p.tap_dy[p.tap0 + t], dx = p.tap_dx[p.tap0 + t];
+            const int xk = (yy * p.stride + dy) * p.tiw + (kh * 16 + 8 * khalf + rq) * p.stride + dx;
+            const unsigned char* bp = xt + xk * PSX + colbase * 2;
+            const half4 lo = tr_read(bp), hi = tr_read(bp + 4 * p.stride * PSX);
+            const half8 b = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[ai][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b, acc[ai][m], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // ---- partial dW block -> workspace[worker][co][ci][tap]
+  const int CIW = p.ci_tiles * WG_CI;
+  float* wk = p.work + (long)worker * (p.co_tiles * WG_CO) * CIW * p.ntaps_all;
+  const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int ai = 0; ai < 3; ++ai) {
+    const int t = wave + 4 * ai;
+    if (t < p.ntaps) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+          wk[((long)(co0 + m * 32 + row) * CIW + (ci0 + col)) * p.ntaps_all + p.tap0 + t] = acc[ai][m][i];
+        }
+    }
+  }
+}
+
+// dW[row_off[co] + chan_off[ci] + tap_off[t]] += scale * sum over workers (fixed order); the tables are the layer's
+// forward packing tables (convpack.forward_tables), so PixelShuffle row order, concatenation channel order,
+// zero-padded channels and Conv3d holders scatter to the right parameter element
+__global__ void wgrad_reduce_kernel(const float* __restrict__ work, int nworkers, int COW, int CIW, int ntaps, const int* __restrict__ row_off,
+                                    const int* __restrict__ chan_off, const int* __restrict__ tap_off, int cout, int cin, float scale,
+                                    float* __restrict__ dw) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)cout * cin * ntaps;
+  if (i >= total) return;
+  const int t = (int)(i % ntaps);
+  const long q = i / ntaps;
+  const int ci = (int)(q % cin), co = (int)(q / cin);
+  const int ro = row_off[co], cf = chan_off[ci];
+  if (ro < 0 || cf < 0) return;
+  float s = 0.f;
+  const long stride = (long)COW * CIW * ntaps;
+  const long off = ((long)co * CIW + ci) * ntaps + t;
+  for (int w = 0; w < nworkers; ++w) s += work[w * stride + off];
+  dw[(long)ro + cf + tap_off[t]] += s * scale;
+}
+
+}  // namespace
+
+extern "C" int tdvc_pack_conv_weights_indexed(const float* w, const int32_t* row_off, const int32_t* chan_off, const int32_t* tap_off,
+                                              const uint8_t* row_mask, const uint8_t* chan_mask, const uint8_t* tap_mask,
+                                              int cout, int cin, int ntaps, int ck, void* dst, void* stream) {
+  TDVC_CHECK(w && row_off && chan_off && tap_off && row_mask && chan_mask && tap_mask && dst && aligned16(dst),
+             "tdvc_pack_conv_weights_indexed: null / unaligned pointer");
+  const int64_t bytes = tdvc_conv_packed_bytes(cout, cin, ntaps, ck);
+  TDVC_CHECK(bytes > 0, "tdvc_pack_conv_weights_indexed: bad geometry");
+  const int ck8 = ck / 8, nchunks = (cin + ck - 1) / ck, steps = (ntaps * ck8 + 1) / 2;
+  const long total = bytes / 16;
+  hipLaunchKernelGGL(pack_indexed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     w, row_off, chan_off, tap_off, row_mask, chan_mask, tap_mask, cout, cin, ntaps, ck, nchunks, steps, total, reinterpret_cast<half_t*>(dst));
+  return tdvc_launch_status("tdvc_pack_conv_weights_indexed");
+}
+
+static int wgrad_workers(int co_tiles, int ci_tiles, int groups, int nblocks) {
+  int w = 1024 / (co_tiles * ci_tiles * groups);
+  if (w < 1) w = 1;
+  if (w > nblocks) w = nblocks;
+  if (w > 64) w = 64;
+  return w;
+}
+
+extern "C" int64_t tdvc_conv_wgrad_work_floats(int cout, int cin, int ntaps, int N, int Ho, int Wo) {
+  if (cout <= 0 || cin <= 0 || ntaps <= 0 || ntaps > TDVC_MAX_TAPS || N <= 0 || Ho <= 0 || Wo <= 0) return TDVC_EINVAL;
+  const int co_tiles = (cout + WG_CO - 1) / WG_CO, ci_tiles = (cin + WG_CI - 1) / WG_CI, groups = (ntaps + WG_MAXT - 1) / WG_MAXT;
+  const int nblocks = N * ((Ho + WG_TH - 1) / WG_TH) * ((Wo + WG_TW - 1) / WG_TW);
+  return (int64_t)wgrad_workers(co_tiles, ci_tiles, groups, nblocks) * co_tiles * WG_CO * ci_tiles * WG_CI * ntaps;
+}
+
+extern "C" int tdvc_conv_wgrad(const tdvc_fmap* g, const tdvc_fmap* x, int cout, int kh, int kw, int stride, int pad,
+                               int ntaps, const int8_t* tap_dy, const int8_t* tap_dx, const int32_t* row_off, const int32_t* chan_off,
+                               const int32_t* tap_off, float scale, float* dw, float* work, int64_t work_floats, void* stream) {
+  TDVC_CHECK(g && x && dw && work && tap_dy && tap_dx && row_off && chan_off && tap_off, "tdvc_conv_wgrad: null pointer");
+  TDVC_CHECK(fmap_ok16(*g) && fmap_ok16(*x) && g->N == x->N, "tdvc_conv_wgrad: fmaps must be fp16 with matching batch");
+  TDVC_CHECK(stride == 1 || stride == 2, "tdvc_conv_wgrad: stride %d", stride);
+  TDVC_CHECK(ntaps >= 1 && ntaps <= TDVC_MAX_TAPS && kh >= 1 && kh <= 7 && kw >= 1 && kw <= 7, "tdvc_conv_wgrad: bad window");
+  TDVC_CHECK(cout >= 1 && cout <= g->C, "tdvc_conv_wgrad: cout %d > dY channels %d", cout, g->C);
+  const int cin = x->C;
+  const int Ho = (x->H + 2 * pad - kh) / stride + 1, Wo = (x->W + 2 * pad - kw) / stride + 1;
+  TDVC_CHECK(Ho == g->H && Wo == g->W, "tdvc_conv_wgrad: dY is %dx%d, conv output is %dx%d", g->H, g->W, Ho, Wo);
+  TDVC_CHECK(work_floats >= tdvc_conv_wgrad_work_floats(cout, cin, ntaps, x->N, Ho, Wo), "tdvc_conv_wgrad: workspace too small");
+  WgradParams p;
+  p.g = to_dev(*g); p.x = to_dev(*x);
+  p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.pad = pad;
+  p.ntaps_all = ntaps;
+  for (int t = 0; t < ntaps; ++t) {
+    TDVC_CHECK(tap_dy[t] >= 0 && tap_dy[t] < kh && tap_dx[t] >= 0 && tap_dx[t] < kw, "tdvc_conv_wgrad: tap %d outside the window", t);
+    p.tap_dy[t] = tap_dy[t]; p.tap_dx[t] = tap_dx[t];
+  }
+  p.co_tiles = (cout + WG_CO - 1) / WG_CO; p.ci_tiles = (cin + WG_CI - 1) / WG_CI;
+  p.blocks_x = (Wo + WG_TW - 1) / WG_TW; p.blocks_y = (Ho + WG_TH - 1) / WG_TH;
+  p.nblocks = x->N * p.blocks_x * p.blocks_y;
+  p.tih = (WG_TH - 1) * stride + kh; p.tiw = (WG_TW - 1) * stride + kw;
+  const size_t lds = (size_t)WG_TH * WG_TW * PSG + (size_t)p.tih * p.tiw * PSX;
+  TDVC_CHECK(lds <= 160 * 1024, "tdvc_conv_wgrad: LDS plan %zu bytes too large", lds);
+  p.work = work;
+  const int groups = (ntaps + WG_MAXT - 1) / WG_MAXT;
+  const int workers = wgrad_workers(p.co_tiles, p.ci_tiles, groups, p.nblocks);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (err != hipSuccess) { tdvc_set_error("tdvc_conv_wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(err)); return (int)err; }
+    attr_done = true;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int gI = 0; gI < groups; ++gI) {
+    p.tap0 = gI * WG_MAXT;
+    p.ntaps = ntaps - p.tap0 < WG_MAXT ? ntaps - p.tap0 : WG_MAXT;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.co_tiles * p.ci_tiles, workers), dim3(256), lds, st, p);
+  }
+  const long total = (long)cout * cin * ntaps;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, work, workers, p.co_tiles * WG_CO,
+                     p.ci_tiles * WG_CI, ntaps, row_off, chan_off, tap_off, cout, cin, scale, dw);
+  return tdvc_launch_status("tdvc_conv_wgrad");
+}

@@ -38,13 +38,12 @@ def pk_conv(owner: PackCache, name: str, conv: nn.Module, **kw) -> ops.PackedCon
         w = conv.weight
         if w.dim() == 5:                       # Conv3d holders
             co, ci, kt, kh, kw_ = w.shape
-            if kt == 1:                        # (1,3,3): a 2-D conv applied to every frame
-                w2, stride, pad = w.reshape(co, ci, kh, kw_), 1, conv.padding[-1]
-            else:                              # (3,1,1) stride 3: 1x1 conv over T*C channels, t-major
-                w2, stride, pad = w.permute(0, 2, 1, 3, 4).reshape(co, kt * ci, 1, 1), 1, 0
-        else:
-            w2, stride, pad = w, conv.stride[0], conv.padding[0]
-        return ops.pack_conv(w2, conv.bias, stride=stride, pad=pad, device=w.device, **kw)
+            if kt == 1:                        # (1,3,3): a 2-D conv applied to every frame (a view of the parameter)
+                return ops.pack_conv(w.view(co, ci, kh, kw_), conv.bias, stride=1, pad=conv.padding[-1], device=w.device, **kw)
+            # (3,1,1) stride 3: 1x1 conv over T*C channels, t-major, gathered straight from the 5-D parameter
+            return ops.pack_conv(w, conv.bias, stride=1, pad=0, device=w.device,
+                                 layout=ops.convpack.WeightLayout.conv3d_temporal(co, ci, kt), **kw)
+        return ops.pack_conv(w, conv.bias, stride=conv.stride[0], pad=conv.padding[0], device=w.device, **kw)
     return owner._pk(name, build)
 
 

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
+from . import convpack
 from ._lib import (ACT_CLAMP01, ACT_LRELU, ACT_NONE, ACT_RELU, GDN_FWD, GDN_INV, GDN_NONE, OUT_NCHW_F32,  # noqa: F401
                    OUT_NHWC, OUT_SHUFFLE2)
 
@@ -121,6 +122,22 @@ class PackedConv:
     cin_real: int = 0        # un-padded input channels (algorithmic FLOP accounting)
     s2d: bool = False        # stride-2 3x3 conv executed as a 2x2 conv over a space-to-depth view
     flops_per_px: float = 0.0  # algorithmic FLOP per OUTPUT pixel of the ORIGINAL conv
+    # --- provenance for re-packing after an optimizer step and for the backward pass (training path)
+    wsrc: torch.Tensor | None = None       # the fp32 weight (nn.Parameter or tensor) on the device
+    bsrc: torch.Tensor | None = None
+    layout: convpack.WeightLayout | None = None
+    tables: convpack.PackTables | None = None
+    orig: dict | None = None               # geometry of the ORIGINAL conv: stride, pad, taps, cin_perm, kh, kw
+    dgrad: "PackedConv | None" = None      # lazily built data-gradient conv (ops.conv_dgrad)
+
+    def repack(self):
+        """re-pack from the (updated) fp32 parameters: one kernel launch, plus the bias gather"""
+        _pack_from_tables(self.wsrc, self.tables, self.w)
+        if self.bsrc is not None:
+            b = self.bsrc.detach().float()
+            self.bias[:self.cout] = b[torch.from_numpy(convpack.shuffle_perm(self.cout)).to(b.device)] if self.shuffle else b
+        if self.dgrad is not None:
+            self.dgrad.repack()
 
 
 def _cout_pad(cout):
@@ -130,7 +147,8 @@ def _cout_pad(cout):
 def _s2d_weights(w: torch.Tensor) -> torch.Tensor:
     """(cout, C, 3, 3) stride-2 pad-1 kernel -> (cout, 4C, 2, 2) stride-1 kernel over the 2x2
     space-to-depth view: virtual channel q*C + c = parity (py, px) = (q>>1, q&1); virtual tap (dy, dx)
-    covers original kernel row ky = 2*dy + py - 1 (zero weight when outside 0..2)."""
+    covers original kernel row ky = 2*dy + py - 1 (zero weight when outside 0..2).  Reference form of
+    `convpack.forward_tables_s2d` (tests)."""
     cout, C_, kh, kw = w.shape
     assert (kh, kw) == (3, 3)
     w2 = torch.zeros(cout, 4 * C_, 2, 2)
@@ -145,50 +163,71 @@ def _s2d_weights(w: torch.Tensor) -> torch.Tensor:
     return w2
 
 
+def _pack_from_tables(wsrc: torch.Tensor, tb: convpack.PackTables, dst: torch.Tensor | None = None) -> torch.Tensor:
+    lib = L.lib()
+    nbytes = lib.tdvc_conv_packed_bytes(tb.cout, tb.cin, len(tb.taps), tb.ck)
+    assert nbytes > 0
+    w = wsrc.detach()
+    assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
+    if dst is None:
+        dst = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    assert dst.numel() == nbytes
+    L.check(lib.tdvc_pack_conv_weights_indexed(w.data_ptr(), tb.row_off.data_ptr(), tb.chan_off.data_ptr(), tb.tap_off.data_ptr(),
+                                               tb.row_mask.data_ptr(), tb.chan_mask.data_ptr(), tb.tap_mask.data_ptr(),
+                                               tb.cout, tb.cin, len(tb.taps), tb.ck, dst.data_ptr(), _stream()), "pack_conv_weights_indexed")
+    return dst
+
+
+def _pick_ck(cin, cout, kh, kw, stride, pad):
+    if (stride == 1 or (stride == 2 and kh == 1 and kw == 1 and pad == 0)) and cin >= 32 and cout >= 64:
+        return 32            # the weight-stationary / pipelined kernels stream 32-channel chunks
+    ck = L.lib().tdvc_conv_plan(cin, kh, kw, stride)
+    L.check(0 if ck > 0 else ck, "conv_plan")
+    return ck
+
+
 def pack_conv(weight: torch.Tensor, bias: torch.Tensor | None, stride=1, pad=0, cin_pad: int | None = None,
-              taps=None, shuffle=False, cin_perm=None, device="cuda", ck=None, allow_s2d=True) -> PackedConv:
-    """weight (cout, cin, kh, kw) fp32 (any device).  `taps`: list of (dy,dx) to keep (masked
-    convs); `shuffle`: rows permuted for the PixelShuffle(2) store; `cin_perm`: index list applied
-    to input channels (free re-ordering of concatenated inputs)."""
-    w = weight.detach().float().cpu()
-    cout, cin_real, kh, kw = w.shape
-    if cin_perm is not None:
-        w = w[:, cin_perm]
-    if (allow_s2d and stride == 2 and (kh, kw) == (3, 3) and pad == 1 and cin_real % 32 == 0 and cout >= 64
-            and taps is None and not shuffle and ck is None):
-        pc = pack_conv(_s2d_weights(w), bias, stride=1, pad=1, device=device, ck=32, allow_s2d=False)
-        pc.s2d, pc.cin, pc.cin_real = True, cin_real, cin_real
-        pc.flops_per_px = 2.0 * cout * cin_real * 9
-        return pc
-    b = torch.zeros(cout) if bias is None else bias.detach().float().cpu()
+              taps=None, shuffle=False, cin_perm=None, device="cuda", ck=None, allow_s2d=True,
+              layout: convpack.WeightLayout | None = None) -> PackedConv:
+    """weight (cout, cin, kh, kw) fp32 (moved to `device` if it is not there; an nn.Parameter on the device is
+    referenced, not copied, so `PackedConv.repack()` sees optimizer updates).  `taps`: list of (dy,dx) to keep
+    (masked convs); `shuffle`: rows permuted for the PixelShuffle(2) store; `cin_perm`: index list applied to
+    input channels (free re-ordering of concatenated inputs); `layout`: how the logical weight sits in the
+    parameter's storage when it is not the dense (cout, cin, kh, kw) order (Conv3d holders)."""
+    wsrc = weight if (weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous()) else \
+        weight.detach().float().contiguous().to(device)
+    dev = wsrc.device
+    if layout is None:
+        cout, cin_real, kh, kw = weight.shape
+        layout = convpack.WeightLayout.dense(cout, cin_real, kh, kw)
+    cout, kh, kw = layout.cout, layout.kh, layout.kw
+    cin_real = layout.cin if cin_perm is None else len(cin_perm)
+    bsrc = None if bias is None else (bias if bias.is_cuda else bias.detach().float().to(dev))
+    orig = dict(stride=stride, pad=pad, taps=taps, cin_perm=cin_perm, kh=kh, kw=kw)
+    s2d = (allow_s2d and stride == 2 and (kh, kw) == (3, 3) and pad == 1 and cin_real % 32 == 0 and cout >= 64
+           and taps is None and not shuffle and ck is None and cin_perm is None and cin_pad is None)
     if shuffle:
         assert cout % 4 == 0
-        cq = cout // 4
-        # packed row (i*2+j)*cq + c  <-  original row c*4 + i*2 + j
-        perm = torch.arange(cout).view(cq, 4).t().reshape(-1)
-        w, b = w[perm], b[perm]
-    cin = pad8(cin_real) if cin_pad is None else cin_pad
-    if taps is None:
-        taps = [(dy, dx) for dy in range(kh) for dx in range(kw)]
-    lib = L.lib()
-    if ck is None:
-        if (stride == 1 or (stride == 2 and kh == 1 and kw == 1 and pad == 0)) and cin >= 32 and cout >= 64:
-            ck = 32          # the weight-stationary / pipelined kernels stream 32-channel chunks
-        else:
-            ck = lib.tdvc_conv_plan(cin, kh, kw, stride)
-            L.check(0 if ck > 0 else ck, "conv_plan")
-    nbytes = lib.tdvc_conv_packed_bytes(cout, cin, len(taps), ck)
-    assert nbytes > 0
-    dst = np.zeros(nbytes // 2, dtype=np.uint16)
-    wn = np.ascontiguousarray(w.numpy())
-    dy = np.array([t[0] for t in taps], dtype=np.int8)
-    dx = np.array([t[1] for t in taps], dtype=np.int8)
-    L.check(lib.tdvc_pack_conv_weights(wn.ctypes.data, cout, cin_real, cin, kh, kw, len(taps),
-                                       dy.ctypes.data, dx.ctypes.data, ck, dst.ctypes.data), "pack_conv_weights")
-    bp = torch.zeros(_cout_pad(cout))
-    bp[:cout] = b
-    return PackedConv(torch.from_numpy(dst.view(np.uint8)).to(device), bp.to(device), cout, cin, kh, kw, stride, pad,
-                      ck, taps, shuffle, cin_real)
+    if s2d:
+        tb = convpack.forward_tables_s2d(layout, ck=32, device=dev)
+        cin, k_stride, k_pad = cin_real, 1, 1
+    else:
+        cin = pad8(cin_real) if cin_pad is None else cin_pad
+        if taps is None:
+            taps = [(dy, dx) for dy in range(kh) for dx in range(kw)]
+        if ck is None:
+            ck = _pick_ck(cin, cout, kh, kw, stride, pad)
+        tb = convpack.forward_tables(layout, cin_pad=cin, taps=taps, pad=pad, ck=ck, shuffle=shuffle, cin_perm=cin_perm, device=dev)
+        k_stride, k_pad = stride, pad
+    orig["taps"] = [(dy, dx) for dy in range(kh) for dx in range(kw)] if orig["taps"] is None else list(orig["taps"])
+    bp = torch.zeros(_cout_pad(cout), dtype=torch.float32, device=dev)
+    pc = PackedConv(_pack_from_tables(wsrc, tb), bp, cout, cin, tb.kh, tb.kw, k_stride, k_pad, tb.ck, tb.taps, shuffle, cin_real,
+                    s2d=s2d, flops_per_px=2.0 * cout * cin_real * 9 if s2d else 0.0,
+                    wsrc=wsrc, bsrc=bsrc, layout=layout, tables=tb, orig=orig)
+    if bsrc is not None:
+        b = bsrc.detach().float()
+        bp[:cout] = b[torch.from_numpy(convpack.shuffle_perm(cout)).to(dev)] if shuffle else b
+    return pc
 
 
 def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, res: FM | None = None,
@@ -247,6 +286,86 @@ def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, 
         return ret
     L.check(L.lib().tdvc_conv2d(C.byref(d), _stream()), "conv2d")
     return ret
+
+
+# ----------------------------------------------------------------------------- conv backward (training path)
+def act_backward(g: FM, y: FM, act, slope=0.0, res: FM | None = None, out: FM | None = None) -> FM:
+    """g * act'(z); the sign of the pre-activation comes from the stored output y (minus its residual)"""
+    out = g if out is None else out
+    dg, dy, do = g.desc(), y.desc(), out.desc()
+    dr = res.desc() if res is not None else None
+    L.check(L.lib().tdvc_act_backward(C.byref(dg), C.byref(dy), C.byref(dr) if dr is not None else None, act, slope, C.byref(do), _stream()),
+            "act_backward")
+    return out
+
+
+def pixel_unshuffle(y: FM, out: FM | None = None) -> FM:
+    """(N, 2H, 2W, C) -> (N, H, W, 4C), channel (i*2+j)*C + c: the gradient of a sub-pixel conv in packed-row order"""
+    if out is None:
+        out = FM.empty(y.N, y.H // 2, y.W // 2, 4 * y.C, dtype=y.t.dtype, device=y.t.device)
+    dy, do = y.desc(), out.desc()
+    L.check(L.lib().tdvc_pixel_unshuffle(C.byref(dy), C.byref(do), _stream()), "pixel_unshuffle")
+    return out
+
+
+def _dgrad_conv(pc: PackedConv, g_channels: int, x_channels: int) -> PackedConv:
+    """the conv that maps dY to dX for the layer `pc` (built once, re-packed with it)"""
+    if pc.dgrad is None:
+        o = pc.orig
+        tb0 = dict(g_channels=g_channels, x_channels=x_channels, taps=o["taps"], pad=o["pad"], stride=o["stride"], shuffle=pc.shuffle,
+                   cin_perm=o["cin_perm"], device=pc.w.device)
+        rows = x_channels * (4 if o["stride"] == 2 else 1)
+        kk = 3 if (o["stride"] == 2 and o["kh"] == 3) else o["kh"]
+        ck = _pick_ck(g_channels, rows, kk, kk, 1, 1)
+        tb = convpack.dgrad_tables(pc.layout, ck=ck, **tb0)
+        bias = torch.zeros(_cout_pad(tb.cout), dtype=torch.float32, device=pc.w.device)
+        pc.dgrad = PackedConv(_pack_from_tables(pc.wsrc, tb), bias, tb.cout, tb.cin, tb.kh, tb.kw, 1, tb.pad, tb.ck, tb.taps, tb.shuffle,
+                              tb.cin, wsrc=pc.wsrc, tables=tb)
+    assert pc.dgrad.cin == g_channels
+    return pc.dgrad
+
+
+def conv_dgrad(pc: PackedConv, g: FM, dx: FM, accumulate=True) -> FM:
+    """dX (+)= dL/dx of y = conv(x, W) given g = dL/dy (pre-activation).  Runs on the forward conv kernels with
+    the weights packed transposed / mirrored (`convpack.dgrad_tables`); for a sub-pixel layer `g` is the
+    un-shuffled gradient (`pixel_unshuffle`), for a stride-2 layer the result is stored through PixelShuffle."""
+    dpc = _dgrad_conv(pc, g.C, dx.C)
+    return conv(g, dpc, out=dx, res=dx if accumulate else None)
+
+
+def conv_wgrad(pc: PackedConv, g: FM, x: FM, dw: torch.Tensor, scale=1.0) -> None:
+    """dW += scale * dL/dW (fp32, the parameter's own layout); `g` as in conv_dgrad"""
+    o = pc.orig
+    tb = pc.__dict__.get("_wg_tables")
+    if tb is None:                               # plain-geometry tables (also for layers that RUN in space-to-depth form)
+        tb = convpack.forward_tables(pc.layout, cin_pad=x.C, taps=o["taps"], pad=o["pad"], ck=8, shuffle=pc.shuffle, cin_perm=o["cin_perm"],
+                                     device=pc.w.device)
+        pc.__dict__["_wg_tables"] = tb
+    assert dw.is_cuda and dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == pc.wsrc.numel()
+    lib = L.lib()
+    Ho, Wo = g.H, g.W
+    nwork = lib.tdvc_conv_wgrad_work_floats(pc.cout, x.C, len(o["taps"]), x.N, Ho, Wo)
+    work = torch.empty((nwork,), dtype=torch.float32, device=dw.device)
+    dy = (C.c_int8 * len(o["taps"]))(*[t[0] for t in o["taps"]])
+    dxs = (C.c_int8 * len(o["taps"]))(*[t[1] for t in o["taps"]])
+    dg, dxd = g.desc(), x.desc()
+    L.check(lib.tdvc_conv_wgrad(C.byref(dg), C.byref(dxd), pc.cout, o["kh"], o["kw"], o["stride"], o["pad"], len(o["taps"]), dy, dxs,
+                                tb.row_off.data_ptr(), tb.chan_off.data_ptr(), tb.tap_off.data_ptr(), scale, dw.data_ptr(),
+                                work.data_ptr(), nwork, _stream()), "conv_wgrad")
+
+
+def conv_bgrad(pc: PackedConv, g: FM, db: torch.Tensor, scale=1.0) -> None:
+    """db += scale * sum over batch and pixels of g (rows un-permuted for sub-pixel layers)"""
+    lib = L.lib()
+    idx = pc.__dict__.get("_bg_index")
+    if idx is None and pc.shuffle:
+        idx = torch.from_numpy(convpack.shuffle_perm(pc.cout)).to(torch.int32).to(db.device)
+        pc.__dict__["_bg_index"] = idx
+    nwork = lib.tdvc_bias_grad_work_floats(g.N, g.C)
+    work = torch.empty((nwork,), dtype=torch.float32, device=db.device)
+    dg = g.desc()
+    L.check(lib.tdvc_bias_grad(C.byref(dg), pc.cout, idx.data_ptr() if idx is not None else None, scale, db.data_ptr(), work.data_ptr(), nwork,
+                               _stream()), "bias_grad")
 
 
 def dcn_fused(x: FM, om: FM, pc: PackedConv, out: FM, groups=8, act=ACT_NONE, slope=0.0, round16=True) -> FM:

@@ -1,0 +1,107 @@
+"""Conv backward (data / weight / bias gradients) vs torch autograd in fp32 on the same fp16-rounded operands."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import assert_close, fm_to_cpu, randn, rnd16, to_fm
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from tdvc_amd import ops
+    return ops
+
+
+CASES = [
+    # name, N, cin, cout, k, stride, pad, H, W, shuffle
+    ("3x3_64_64", 2, 64, 64, 3, 1, 1, 40, 72, False),
+    ("3x3_64_64_large", 1, 64, 64, 3, 1, 1, 96, 128, False),       # dgrad on the LDS-DMA kernel
+    ("3x3_3_64", 2, 3, 64, 3, 1, 1, 33, 47, False),
+    ("3x3_128_192", 1, 128, 192, 3, 1, 1, 17, 30, False),
+    ("1x1_128_64", 2, 128, 64, 1, 1, 0, 20, 36, False),
+    ("7x7_8_32", 1, 8, 32, 7, 1, 3, 34, 60, False),
+    ("7x7_32_16", 1, 32, 16, 7, 1, 3, 19, 25, False),
+    ("3x3_s2_64_128", 2, 64, 128, 3, 2, 1, 32, 48, False),         # space-to-depth forward, sub-pixel dgrad
+    ("1x1_s2_64_128", 1, 64, 128, 1, 2, 0, 32, 64, False),
+    ("subpel_128_64", 1, 128, 256, 3, 1, 1, 12, 20, True),          # conv + PixelShuffle(2)
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_backward(case, report):
+    ops = _ops()
+    name, N, cin, cout, k, stride, pad, H, W, shuffle = case
+    x = rnd16(randn(N, cin, H, W, seed=101))
+    w = rnd16(randn(cout, cin, k, k, seed=102) * (1.0 / (cin * k * k) ** 0.5))
+    b = randn(cout, seed=103) * 0.1
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    y = F.conv2d(xr, wr, br, stride=stride, padding=pad)
+    if shuffle:
+        y = F.pixel_shuffle(y, 2)
+    gy = rnd16(randn(*y.shape, seed=104) * 0.5)
+    gx, gw, gb = torch.autograd.grad(y, (xr, wr, br), gy)
+
+    wd, bd = w.cuda(), b.cuda()
+    pc = ops.pack_conv(wd, bd, stride=stride, pad=pad, shuffle=shuffle)
+    xf = to_fm(x, ops)
+    yf = ops.conv(xf, pc)
+    assert_close(fm_to_cpu(yf, y.shape[1]), y.detach(), 2e-3, 2e-3, f"fwd {name}", report)
+    g = to_fm(gy, ops)
+    gq = ops.pixel_unshuffle(g) if shuffle else g
+    # data gradient, accumulated onto a non-zero buffer
+    base = rnd16(randn(N, cin, H, W, seed=105) * 0.1)
+    dx = to_fm(base, ops)
+    ops.conv_dgrad(pc, gq, dx, accumulate=True)
+    scale = float(gx.abs().max())
+    assert_close(fm_to_cpu(dx, cin), gx + base, 3e-3, 3e-3 * max(1.0, scale), f"dgrad {name}", report)
+    # weight / bias gradients accumulate into fp32 buffers
+    dw = torch.full_like(wd, 0.25)
+    db = torch.full_like(bd, -0.5)
+    ops.conv_wgrad(pc, gq, xf, dw)
+    ops.conv_bgrad(pc, gq, db)
+    tol_w = 2e-3 * float(gw.abs().max()) + 1e-3
+    assert_close(dw.cpu() - 0.25, gw, 2e-3, tol_w, f"wgrad {name}", report)
+    assert_close(db.cpu() + 0.5, gb, 2e-3, 2e-3 * float(gb.abs().max()) + 1e-3, f"bgrad {name}", report)
+    # bitwise reproducible
+    dw2 = torch.full_like(wd, 0.25)
+    ops.conv_wgrad(pc, gq, xf, dw2)
+    assert torch.equal(dw, dw2)
+
+
+def test_repack_follows_parameter_updates(report):
+    """PackedConv references the device parameter: an in-place update + repack() changes forward and dgrad"""
+    ops = _ops()
+    w = torch.nn.Parameter(rnd16(randn(64, 64, 3, 3, seed=111) * 0.05).cuda())
+    b = torch.nn.Parameter((randn(64, seed=112) * 0.1).cuda())
+    pc = ops.pack_conv(w, b, stride=1, pad=1)
+    x = rnd16(randn(1, 64, 24, 40, seed=113))
+    xf = to_fm(x, ops)
+    y0 = fm_to_cpu(ops.conv(xf, pc))
+    g = to_fm(rnd16(randn(1, 64, 24, 40, seed=114)), ops)
+    dx0 = fm_to_cpu(ops.conv_dgrad(pc, g, ops.FM.zeros(1, 24, 40, 64), accumulate=False))
+    with torch.no_grad():
+        w.mul_(0.5)
+        b.add_(1.0)
+    pc.repack()
+    y1 = fm_to_cpu(ops.conv(xf, pc))
+    dx1 = fm_to_cpu(ops.conv_dgrad(pc, g, ops.FM.zeros(1, 24, 40, 64), accumulate=False))
+    ref = F.conv2d(x, w.detach().cpu(), b.detach().cpu(), padding=1)
+    assert_close(y1, ref, 2e-3, 2e-3, "forward after repack", report)
+    assert_close(dx1, 0.5 * dx0, 2e-3, 2e-3, "dgrad after repack", report)
+    assert not torch.allclose(y0, y1)
+
+
+def test_act_backward_and_unshuffle(report):
+    ops = _ops()
+    y = rnd16(randn(2, 64, 9, 13, seed=121))
+    r = rnd16(randn(2, 64, 9, 13, seed=122))
+    g = rnd16(randn(2, 64, 9, 13, seed=123))
+    out = ops.act_backward(to_fm(g, ops), to_fm(y, ops), ops.ACT_LRELU, 0.1, res=to_fm(r, ops), out=ops.FM.empty(2, 9, 13, 64))
+    ref = torch.where(y - r > 0, g, rnd16(g * 0.1))
+    assert_close(fm_to_cpu(out), ref, 1e-3, 1e-3, "act_backward lrelu + residual", report)
+    out = ops.act_backward(to_fm(g, ops), to_fm(y, ops), ops.ACT_RELU)
+    assert_close(fm_to_cpu(out), torch.where(y > 0, g, torch.zeros_like(g)), 0, 0, "act_backward relu", report)
+    z = rnd16(randn(1, 16, 8, 10, seed=124))
+    u = fm_to_cpu(ops.pixel_unshuffle(to_fm(z, ops)))
+    assert torch.equal(u, z.view(1, 16, 4, 2, 5, 2).permute(0, 3, 5, 1, 2, 4).reshape(1, 64, 4, 5))

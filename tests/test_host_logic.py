@@ -74,12 +74,107 @@ def test_fm_views_address_arithmetic():
     assert f32.f32 and f32.desc().dtype == 1
 
 
-def test_pack_conv_host_options():
-    w = torch.randn(16, 6, 3, 3)
-    pc = ops.pack_conv(w, torch.randn(16), stride=1, pad=1, device="cpu")
-    assert pc.cin == 8 and pc.cin_real == 6 and pc.ck == 8 and pc.bias.numel() == 32 and len(pc.taps) == 9
-    pc = ops.pack_conv(torch.randn(512, 128, 3, 3), None, stride=1, pad=1, shuffle=True, device="cpu")
-    assert pc.shuffle and pc.cout == 512 and pc.bias.numel() == 512 and pc.ck == 32
+def _emulate_indexed_pack(w_flat, tb):
+    """numpy restatement of pack_indexed_kernel: (row, channel, tap) -> value"""
+    ro, co_, to = tb.row_off.numpy(), tb.chan_off.numpy(), tb.tap_off.numpy()
+    rm, cm, tm = tb.row_mask.numpy(), tb.chan_mask.numpy(), tb.tap_mask.numpy()
+    out = np.zeros((tb.cout, tb.cin, len(tb.taps)), dtype=np.float32)
+    for r in range(tb.cout):
+        for t in range(len(tb.taps)):
+            if ro[r] < 0 or (tm[t] & rm[r]):
+                continue
+            ok = (co_ >= 0) & ((tm[t] & cm) == 0)
+            out[r, ok, t] = w_flat[ro[r] + co_[ok] + to[t]]
+    return out
+
+
+def _dense_rct(w, taps):
+    """(cout, cin, kh, kw) -> (cout, cin, ntaps) in tap-list order"""
+    return np.stack([w[:, :, dy, dx] for dy, dx in taps], axis=2)
+
+
+def test_pack_tables_forward_forms():
+    from tdvc_amd import convpack as cp
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal((16, 6, 3, 3)).astype(np.float32)
+    full = [(dy, dx) for dy in range(3) for dx in range(3)]
+    lay = cp.WeightLayout.dense(16, 6, 3, 3)
+    # zero-padded channels
+    tb = cp.forward_tables(lay, cin_pad=8, taps=full, pad=1, ck=8, device="cpu")
+    got = _emulate_indexed_pack(w.reshape(-1), tb)
+    assert np.array_equal(got[:, :6], _dense_rct(w, full)) and not got[:, 6:].any()
+    assert tb.tap_lin.tolist() == list(range(9))
+    # masked tap list + channel permutation (concatenation order)
+    taps = [(0, 0), (0, 1), (1, 0)]
+    perm = [3, 4, 5, 0, 1, 2]
+    tb = cp.forward_tables(lay, cin_pad=8, taps=taps, pad=1, ck=8, cin_perm=perm, device="cpu")
+    assert np.array_equal(_emulate_indexed_pack(w.reshape(-1), tb)[:, :6], _dense_rct(w[:, perm], taps))
+    # PixelShuffle row order
+    w4 = rng.standard_normal((8, 4, 3, 3)).astype(np.float32)
+    tb = cp.forward_tables(cp.WeightLayout.dense(8, 4, 3, 3), cin_pad=8, taps=full, pad=1, ck=8, shuffle=True, device="cpu")
+    rows = torch.arange(8).view(2, 4).t().reshape(-1).numpy()
+    assert np.array_equal(_emulate_indexed_pack(w4.reshape(-1), tb)[:, :4], _dense_rct(w4[rows], full))
+    # space-to-depth form of a 3x3 stride-2 conv == ops._s2d_weights
+    ws = rng.standard_normal((64, 32, 3, 3)).astype(np.float32)
+    tb = cp.forward_tables_s2d(cp.WeightLayout.dense(64, 32, 3, 3), ck=32, device="cpu")
+    ref = ops._s2d_weights(torch.from_numpy(ws)).numpy()
+    assert (tb.kh, tb.kw, tb.pad, tb.cin) == (2, 2, 1, 128)
+    assert np.array_equal(_emulate_indexed_pack(ws.reshape(-1), tb), _dense_rct(ref, tb.taps))
+    # Conv3d (3,1,1) holder gathered from the 5-D parameter
+    w5 = rng.standard_normal((8, 4, 3, 1, 1)).astype(np.float32)
+    lay5 = cp.WeightLayout.conv3d_temporal(8, 4, 3)
+    tb = cp.forward_tables(lay5, cin_pad=16, taps=[(0, 0)], pad=0, ck=8, device="cpu")
+    ref5 = np.transpose(w5, (0, 2, 1, 3, 4)).reshape(8, 12, 1, 1)
+    assert np.array_equal(_emulate_indexed_pack(w5.reshape(-1), tb)[:, :12], _dense_rct(ref5, [(0, 0)]))
+
+
+def test_pack_tables_dgrad_forms():
+    """the data-gradient conv built from the tables == autograd's input gradient (dense evaluation on the CPU)"""
+    import torch.nn.functional as F
+    from tdvc_amd import convpack as cp
+    g = torch.Generator().manual_seed(3)
+
+    def run_packed(tb, w_flat, gy):
+        """evaluate the conv the tables describe: input gy (N, tb.cin, H, W) -> (N, tb.cout, H, W) (+ PixelShuffle)"""
+        wd = torch.from_numpy(_emulate_indexed_pack(w_flat, tb))              # (rows, chans, ntaps)
+        wk = torch.zeros(tb.cout, tb.cin, tb.kh, tb.kw)
+        for t, (dy, dx) in enumerate(tb.taps):
+            wk[:, :, dy, dx] = wd[:, :, t]
+        y = F.conv2d(gy, wk, None, padding=tb.pad)
+        if tb.shuffle:                          # packed row (i*2+j)*cq + c -> pixel (2y+i, 2x+j), channel c
+            N, C4, H, W = y.shape
+            y = y.view(N, 2, 2, C4 // 4, H, W).permute(0, 3, 4, 1, 5, 2).reshape(N, C4 // 4, 2 * H, 2 * W)
+        return y
+
+    for (cout, cin, k, stride, pad, H, W) in [(8, 6, 3, 1, 1, 7, 9), (8, 6, 1, 1, 0, 5, 6), (16, 8, 3, 2, 1, 8, 12), (16, 8, 1, 2, 0, 8, 10),
+                                              (8, 4, 7, 1, 3, 9, 9)]:
+        w = torch.randn(cout, cin, k, k, generator=g)
+        x = torch.randn(2, cin, H, W, generator=g, requires_grad=True)
+        y = F.conv2d(x, w, None, stride=stride, padding=pad)
+        gy = torch.randn(y.shape, generator=g)
+        (gx,) = torch.autograd.grad(y, x, gy)
+        taps = [(dy, dx) for dy in range(k) for dx in range(k)]
+        tb = cp.dgrad_tables(cp.WeightLayout.dense(cout, cin, k, k), g_channels=cout, x_channels=cin, taps=taps, pad=pad, stride=stride,
+                             ck=8, device="cpu")
+        got = run_packed(tb, w.numpy().reshape(-1), gy)
+        assert got.shape == gx.shape, (got.shape, gx.shape)
+        assert torch.allclose(got, gx, atol=1e-4, rtol=1e-4), f"dgrad tables k={k} stride={stride}: {float((got - gx).abs().max())}"
+    # sub-pixel forward conv (conv + PixelShuffle): dX = dgrad conv over the un-shuffled dY in packed-row order
+    cout, cin, H, W = 16, 6, 5, 7
+    w = torch.randn(cout, cin, 3, 3, generator=g)
+    x = torch.randn(1, cin, H, W, generator=g, requires_grad=True)
+    y = F.pixel_shuffle(F.conv2d(x, w, None, padding=1), 2)
+    gy = torch.randn(y.shape, generator=g)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    taps = [(dy, dx) for dy in range(3) for dx in range(3)]
+    tb = cp.dgrad_tables(cp.WeightLayout.dense(cout, cin, 3, 3), g_channels=cout, x_channels=cin, taps=taps, pad=1, stride=1, ck=8,
+                         shuffle=True, device="cpu")
+    cq = cout // 4
+    gun = gy.view(1, cq, H, 2, W, 2).permute(0, 3, 5, 1, 2, 4).reshape(1, cout, H, W)      # channel (i*2+j)*cq + c
+    assert torch.allclose(run_packed(tb, w.numpy().reshape(-1), gun), gx, atol=1e-4, rtol=1e-4)
+
+
+def test_masked_conv_taps():
     from tdvc_amd.model.coder import MaskedConv2d
     mc = MaskedConv2d(8, 16, kernel_size=5, padding=2)
     taps = mc.live_taps()
