@@ -290,6 +290,29 @@ int tdvc_pixel_unshuffle(const tdvc_fmap* y, const tdvc_fmap* out, void* stream)
 int64_t tdvc_bias_grad_work_floats(int N, int C);
 int tdvc_bias_grad(const tdvc_fmap* g, int nvalid, const int32_t* dst_index, float scale, float* db, float* work, int64_t work_floats, void* stream);
 
+/* ---------------------------------------------------------------- backward of the streaming operators (training path)
+ * Adjoints of the kernels above; every gradient ACCUMULATES into its destination (tdvc_amd/autograd.py). */
+/* dst[..., c] = c < src.C ? src[..., c] : 0 with dtype conversion (fp32 gradients -> the fp16 MFMA backward kernels). */
+int tdvc_copy_cast(const tdvc_fmap* src, const tdvc_fmap* dst, void* stream);
+/* g *= [0 < y < 1] (the reconstruction clamp, pnet.py:78). */
+int tdvc_clamp01_backward(const tdvc_fmap* g, const tdvc_fmap* y, void* stream);
+/* y = a * gate[n][c] (SELayer scaling, inflate.py:208): da += g * gate (da may be NULL), dgate[n][c] += sum_pix g * a. */
+int64_t tdvc_gate_backward_work_floats(int N, int C);
+int tdvc_gate_backward(const tdvc_fmap* g, const tdvc_fmap* a, const float* gate, const tdvc_fmap* da, float* dgate, float* work,
+                       int64_t work_floats, void* stream);
+/* backward of tdvc_se_gate: dmean[N][C] (written) and the four parameter gradients (+= scale * ...). */
+int tdvc_se_gate_backward(const float* partial, int nblocks, float inv_count, int N, int C, int Cmid, const float* w1, const float* b1,
+                          const float* w2, const float* b2, const float* gate, const float* dgate, float scale, float* dmean,
+                          float* dw1, float* db1, float* dw2, float* db2, void* stream);
+/* dx[n][pix][c] += v[n][c] * scale (adjoint of the global average pool). */
+int tdvc_bcast_channel_add(const tdvc_fmap* dx, const float* v, float scale, void* stream);
+/* adjoint of tdvc_add_flow: dflow[.., 0/1] += sum of the even / odd channels of doff. */
+int tdvc_add_flow_backward(const tdvc_fmap* doff, const tdvc_fmap* dflow, void* stream);
+/* adjoint of tdvc_bcast_add_act: dx *= lrelu'(x) in place, db += sum over the T channel slices of dx. */
+int tdvc_bcast_add_act_backward(const tdvc_fmap* dx, const tdvc_fmap* x, const tdvc_fmap* db, float slope, void* stream);
+/* adjoint of tdvc_upsample2x: dx += U^T dy. */
+int tdvc_upsample2x_backward(const tdvc_fmap* dy, const tdvc_fmap* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,15 @@ SIGNATURES = {
     "tdvc_pixel_unshuffle": (_i, [_FM, _FM, _P]),
     "tdvc_bias_grad_work_floats": (_i64, [_i, _i]),
     "tdvc_bias_grad": (_i, [_FM, _i, _P, _f, _P, _P, _i64, _P]),
+    "tdvc_copy_cast": (_i, [_FM, _FM, _P]),
+    "tdvc_clamp01_backward": (_i, [_FM, _FM, _P]),
+    "tdvc_gate_backward_work_floats": (_i64, [_i, _i]),
+    "tdvc_gate_backward": (_i, [_FM, _FM, _P, _FM, _P, _P, _i64, _P]),
+    "tdvc_se_gate_backward": (_i, [_P, _i, _f, _i, _i, _i] + [_P] * 6 + [_f] + [_P] * 6),
+    "tdvc_bcast_channel_add": (_i, [_FM, _P, _f, _P]),
+    "tdvc_add_flow_backward": (_i, [_FM, _FM, _P]),
+    "tdvc_bcast_add_act_backward": (_i, [_FM, _FM, _FM, _f, _P]),
+    "tdvc_upsample2x_backward": (_i, [_FM, _FM, _P]),
     "tdvc_conv_wgrad_work_floats": (_i64, [_i] * 6),
     "tdvc_conv_wgrad": (_i, [_FM, _FM] + [_i] * 6 + [_P] * 5 + [_f, _P, _P, _i64, _P]),
     "tdvc_dcn_fused": (_i, [C.POINTER(DcnDesc), _P]),

@@ -1,0 +1,173 @@
+"""Reverse-mode differentiation of the TDVC forward on MI355X (training path).
+
+The forward is a fixed sequence of `ops.*` calls on `FM` views (channel slices of shared buffers stand in for the
+reference's `torch.cat`, in-place kernels for its `x += ...`).  torch.autograd cannot follow writes into views of
+pre-allocated buffers, so the build records its own tape: while `autograd.record()` is active every differentiable
+op appends a closure that, given the gradient of its outputs, ACCUMULATES into the gradients of its inputs.
+
+Gradient storage mirrors activation storage: one gradient buffer per activation buffer (same shape and dtype,
+zero-initialised on first use), addressed through the same view geometry — so a conv that wrote channels 64..127
+of a buffer reads its output gradient from channels 64..127 of the mirror, and the data gradient of a
+`cat`-consumer lands in the producers' slices for free.  Parameter gradients are fp32 `param.grad` tensors; the
+loss scale of mixed-precision training is removed inside the weight-gradient kernels (`scale = 1 / loss_scale`).
+"""
+from __future__ import annotations
+
+import contextlib
+
+import torch
+
+from . import ops
+from .ops import FM
+
+
+class Tape:
+    def __init__(self, loss_scale: float = 1.0):
+        self.nodes: list = []
+        self.gbuf: dict[int, torch.Tensor] = {}
+        self.keep: list = []                      # activation tensors referenced by the closures stay alive
+        self.nograd: set[int] = set()             # base buffers that need no gradient (network inputs)
+        self.loss_scale = float(loss_scale)
+
+    # ------------------------------------------------------------------ gradient views
+    def _base(self, t: torch.Tensor) -> torch.Tensor:
+        key = t.data_ptr()
+        g = self.gbuf.get(key)
+        if g is None:
+            g = torch.zeros_like(t)
+            self.gbuf[key] = g
+            self.keep.append(t)
+        return g
+
+    def grad(self, fm: FM) -> FM:
+        """the gradient view that mirrors `fm`"""
+        return FM(self._base(fm.t), fm.off, fm.N, fm.C, fm.sn)
+
+    def grad_tensor(self, t: torch.Tensor) -> torch.Tensor:
+        return self._base(t)
+
+    def needs_grad(self, fm: FM) -> bool:
+        return fm.t.data_ptr() not in self.nograd
+
+    def mark_input(self, fm: FM):
+        self.nograd.add(fm.t.data_ptr())
+
+    def add(self, fn):
+        self.nodes.append(fn)
+
+    @property
+    def inv_scale(self) -> float:
+        return 1.0 / self.loss_scale
+
+    # ------------------------------------------------------------------ the backward sweep
+    def backward(self):
+        prev, ops._IN_BACKWARD = ops._IN_BACKWARD, True
+        try:
+            for fn in reversed(self.nodes):
+                fn()
+        finally:
+            ops._IN_BACKWARD = prev
+        self.nodes.clear()
+
+
+def param_grad(p: torch.Tensor) -> torch.Tensor:
+    """fp32 gradient accumulator of a parameter (created zeroed)"""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, dtype=torch.float32)
+    return p.grad
+
+
+@contextlib.contextmanager
+def record(loss_scale: float = 1.0):
+    tape = Tape(loss_scale)
+    prev, ops.TAPE = ops.TAPE, tape
+    try:
+        yield tape
+    finally:
+        ops.TAPE = prev
+
+
+def accumulate(dst: FM, src: FM, sign: float = 1.0):
+    """dst += sign * src (same geometry)"""
+    ops.scale_act_res(dst, dst, res=src, res_sign=sign)
+
+
+# ---------------------------------------------------------------------- op records (called from ops.* when taping)
+def record_conv(tape: Tape, x: FM, pc, y, act, slope, res, res2, gdn, aux, square, nchw_out):
+    if gdn != ops.GDN_NONE or square:
+        raise NotImplementedError("autograd: GDN convs are recorded by the coder (record_gdn)")
+    assert not (act not in (ops.ACT_NONE,) and res2 is not None), "autograd: activation + two residuals is not on the path"
+    weight, bias = pc.param_w, pc.param_b
+
+    def bwd():
+        if nchw_out is not None:                  # planar fp32 output (the RGB reconstruction): gradient arrives planar
+            g = ops.from_nchw(tape.grad_tensor(nchw_out), Cpad=ops.pad8(pc.cout))
+            yv = ops.from_nchw(nchw_out, Cpad=ops.pad8(pc.cout))
+        else:
+            g, yv = tape.grad(y), y
+        if res is not None and tape.needs_grad(res):
+            accumulate(tape.grad(res), g)
+        if res2 is not None and tape.needs_grad(res2):
+            accumulate(tape.grad(res2), g)
+        if g.f32:                                 # fp32 outputs (flow, latents): the MFMA backward kernels take fp16
+            g = ops.copy_cast(g, FM.empty(g.N, g.H, g.W, ops.pad8(g.C), device=g.t.device))
+        if act in (ops.ACT_RELU, ops.ACT_LRELU):
+            g = ops.act_backward(g, yv, act, slope, res=res)
+        elif act == ops.ACT_CLAMP01:
+            g = ops.clamp01_backward(g, yv)
+        elif act != ops.ACT_NONE:
+            raise NotImplementedError(f"autograd: activation {act}")
+        gq = ops.pixel_unshuffle(g) if pc.shuffle else g
+        if tape.needs_grad(x):
+            ops.conv_dgrad(pc, gq, tape.grad(x), accumulate=True)
+        ops.conv_wgrad(pc, gq, x, param_grad(weight).view(-1), scale=tape.inv_scale)
+        if bias is not None:
+            ops.conv_bgrad(pc, gq, param_grad(bias), scale=tape.inv_scale)
+
+    tape.add(bwd)
+
+
+def record_scale_act_res(tape: Tape, a: FM, out: FM, gate, act, slope, res, res_sign, out2):
+    def bwd():
+        g = tape.grad(out)
+        if out2 is not None:
+            accumulate(g, tape.grad(out2))
+        if res is not None and tape.needs_grad(res):
+            accumulate(tape.grad(res), g, res_sign)
+        if act != ops.ACT_NONE:
+            raise NotImplementedError("autograd: scale_act_res with an activation")
+        if gate is not None:
+            ops.gate_backward(g, a, gate, tape.grad(a) if tape.needs_grad(a) else None, tape.grad_tensor(gate))
+        elif tape.needs_grad(a):
+            accumulate(tape.grad(a), g)
+
+    tape.add(bwd)
+
+
+def record_se_gate(tape: Tape, x: FM, p, partial, nblocks, gate):
+    params = p.params                             # (conv1.weight, conv1.bias, conv2.weight, conv2.bias) nn.Parameters
+
+    def bwd():
+        dgate = tape.grad_tensor(gate)
+        grads = [param_grad(q) for q in params]
+        dmean = ops.se_gate_backward(p, partial, nblocks, x.H * x.W, gate, dgate, tape.inv_scale, grads)
+        if tape.needs_grad(x):
+            ops.bcast_channel_add(tape.grad(x), dmean, 1.0 / (x.H * x.W))
+
+    tape.add(bwd)
+
+
+def record_add_flow(tape: Tape, off: FM, flow: FM):
+    tape.add(lambda: ops.add_flow_backward(tape.grad(off), tape.grad(flow)))
+
+
+def record_bcast_add_act(tape: Tape, x: FM, b: FM, slope):
+    tape.add(lambda: ops.bcast_add_act_backward(tape.grad(x), x, tape.grad(b), slope))
+
+
+def record_upsample2x(tape: Tape, x: FM, out: FM):
+    def bwd():
+        if tape.needs_grad(x):
+            ops.upsample2x_backward(tape.grad(out), tape.grad(x))
+
+    tape.add(bwd)

@@ -94,6 +94,240 @@ __global__ void reduce_rows_kernel(const float* partial, int rows, int C_, int n
   if (d >= 0) out[d] += s * scale;
 }
 
+// dst[..., c] = c < src.C ? src[..., c] : 0 (any dtypes; dst.C % 8 == 0 when fp16)
+__global__ void copy_cast_kernel(FMap src, FMap dst) {
+  const long npix = (long)dst.H * dst.W;
+  const int chunks = (dst.C + 7) / 8;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * dst.N * chunks) return;
+  const int c = (int)(i % chunks) * 8;
+  const long q = i / chunks;
+  const int n = (int)(q / npix);
+  const long pix = q % npix;
+  float v[8];
+  if (src.f32) {
+    const float* sp = reinterpret_cast<const float*>(src.p) + (long)n * src.sn + pix * src.sp;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (c + j < src.C) ? sp[c + j] : 0.f;
+  } else if (c < src.C) {
+    load8(src, n, pix, c, v);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+  }
+  store8(dst, n, pix, c, v);
+}
+
+// g * [0 < y < 1] (the reconstruction clamp), in place
+__global__ void clamp01_backward_kernel(FMap g, FMap y) {
+  const long npix = (long)g.H * g.W;
+  const int chunks = g.C / 8;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * g.N * chunks) return;
+  const int c = (int)(i % chunks) * 8;
+  const long q = i / chunks;
+  const int n = (int)(q / npix);
+  const long pix = q % npix;
+  float gv[8], yv[8];
+  load8(g, n, pix, c, gv);
+  load8(y, n, pix, c, yv);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) gv[j] = (yv[j] > 0.f && yv[j] < 1.f) ? gv[j] : 0.f;
+  store8(g, n, pix, c, gv);
+}
+
+// y = a * gate[n][c]:  da += g * gate;  partial[(n*nblocks + blk)][c] = sum_pix g * a
+__global__ __launch_bounds__(256) void gate_backward_kernel(FMap g, FMap a, const float* gate, FMap da, float* partial, int nblocks) {
+  __shared__ float red[256][9];
+  const int chunks = g.C / 8;            // <= 32
+  const int lanes = 256 / chunks;
+  const int tid = threadIdx.x;
+  const int ck = tid % chunks, pl = tid / chunks;
+  const int n = blockIdx.y;
+  const long npix = (long)g.H * g.W;
+  const long per = (npix + nblocks - 1) / nblocks;
+  const long p0 = (long)blockIdx.x * per;
+  const long p1 = p0 + per < npix ? p0 + per : npix;
+  float acc[8], gt[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { acc[j] = 0.f; gt[j] = (pl < lanes) ? gate[(long)n * g.C + ck * 8 + j] : 0.f; }
+  if (pl < lanes) {
+    for (long pix = p0 + pl; pix < p1; pix += lanes) {
+      float gv[8], av[8];
+      load8(g, n, pix, ck * 8, gv);
+      load8(a, n, pix, ck * 8, av);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += gv[j] * av[j];
+      if (da.p) {
+        float dv[8];
+        load8(da, n, pix, ck * 8, dv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dv[j] += gv[j] * gt[j];
+        store8(da, n, pix, ck * 8, dv);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[tid][j] = (pl < lanes) ? acc[j] : 0.f;
+  __syncthreads();
+  if (tid < g.C) {
+    const int cc = tid / 8, j = tid % 8;
+    float s = 0.f;
+    for (int l = 0; l < lanes; ++l) s += red[l * chunks + cc][j];
+    partial[((long)n * nblocks + blockIdx.x) * g.C + tid] = s;
+  }
+}
+
+// out[n][c] += sum_blk partial[(n*nblocks + blk)][c]
+__global__ void reduce_groups_kernel(const float* partial, int N, int nblocks, int C_, float* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C_) return;
+  const int n = i / C_, c = i - n * C_;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[((long)n * nblocks + b) * C_ + c];
+  out[i] += s;
+}
+
+// Backward of se_gate_kernel (gate = sigmoid(W2 relu(W1 mean + b1) + b2)): one workgroup, batch items in order.
+// dmean[n][c] (written), dW1 / db1 / dW2 / db2 += scale * ...
+__global__ __launch_bounds__(1024) void se_gate_backward_kernel(const float* partial, int nblocks, float inv_count, int N, int C_, int Cmid,
+                                                                const float* w1, const float* b1, const float* w2, const float* b2,
+                                                                const float* gate, const float* dgate, float scale, float* dmean,
+                                                                float* dw1, float* db1, float* dw2, float* db2) {
+  __shared__ float mean[256], ds[256];
+  __shared__ float mid[32], dmid[32];
+  const int tid = threadIdx.x;
+  for (int n = 0; n < N; ++n) {
+    if (tid < C_) {
+      float s = 0.f;
+      for (int b = 0; b < nblocks; ++b) s += partial[((long)n * nblocks + b) * C_ + tid];
+      mean[tid] = s * inv_count;
+      const float gt = gate[(long)n * C_ + tid];
+      ds[tid] = dgate[(long)n * C_ + tid] * gt * (1.f - gt);             // d pre-sigmoid
+    }
+    __syncthreads();
+    if (tid < Cmid) {
+      float s = b1[tid];
+      for (int c = 0; c < C_; ++c) s += w1[tid * C_ + c] * mean[c];
+      mid[tid] = s > 0.f ? s : 0.f;
+      float d = 0.f;
+      for (int c = 0; c < C_; ++c) d += w2[c * Cmid + tid] * ds[c];
+      dmid[tid] = s > 0.f ? d : 0.f;
+      db1[tid] += scale * dmid[tid];
+    }
+    __syncthreads();
+    if (tid < C_) {
+      db2[tid] += scale * ds[tid];
+      float d = 0.f;
+      for (int j = 0; j < Cmid; ++j) {
+        dw2[tid * Cmid + j] += scale * ds[tid] * mid[j];
+        dw1[j * C_ + tid] += scale * dmid[j] * mean[tid];
+        d += w1[j * C_ + tid] * dmid[j];
+      }
+      dmean[(long)n * C_ + tid] = d;
+    }
+    __syncthreads();
+  }
+}
+
+// dx[n][pix][c] += v[n][c] * scale
+__global__ void bcast_channel_add_kernel(FMap dx, const float* v, float scale) {
+  const long npix = (long)dx.H * dx.W;
+  const int chunks = dx.C / 8;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * dx.N * chunks) return;
+  const int c = (int)(i % chunks) * 8;
+  const long q = i / chunks;
+  const int n = (int)(q / npix);
+  const long pix = q % npix;
+  float d[8];
+  load8(dx, n, pix, c, d);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) d[j] += v[(long)n * dx.C + c + j] * scale;
+  store8(dx, n, pix, c, d);
+}
+
+// off += repeat(flow, C/2): dflow[.., 0/1] += sum over even / odd channels of doff
+__global__ void add_flow_backward_kernel(FMap doff, FMap dflow) {
+  const long npix = (long)doff.H * doff.W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * doff.N) return;
+  const int n = (int)(i / npix);
+  const long pix = i % npix;
+  float sx = 0.f, sy = 0.f;
+  for (int c = 0; c < doff.C; c += 8) {
+    float v[8];
+    load8(doff, n, pix, c, v);
+    sx += v[0] + v[2] + v[4] + v[6];
+    sy += v[1] + v[3] + v[5] + v[7];
+  }
+  float* fp = reinterpret_cast<float*>(dflow.p) + (long)n * dflow.sn + pix * dflow.sp;
+  fp[0] += sx;
+  fp[1] += sy;
+}
+
+// x = lrelu(x_pre + b[c % b.C]) in place:  dx <- dx * lrelu'(x) (in place),  db[c'] += sum over the T slices
+__global__ void bcast_add_act_backward_kernel(FMap dx, FMap x, FMap db, float slope) {
+  const long npix = (long)dx.H * dx.W;
+  const int chunks = db.C / 8;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * dx.N * chunks) return;
+  const int c = (int)(i % chunks) * 8;
+  const long q = i / chunks;
+  const int n = (int)(q / npix);
+  const long pix = q % npix;
+  float acc[8];
+  load8(db, n, pix, c, acc);
+  for (int t = 0; t * db.C < dx.C; ++t) {
+    float g[8], xv[8];
+    load8(dx, n, pix, t * db.C + c, g);
+    load8(x, n, pix, t * db.C + c, xv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { g[j] = xv[j] > 0.f ? g[j] : g[j] * slope; acc[j] += g[j]; }
+    store8(dx, n, pix, t * db.C + c, g);
+  }
+  store8(db, n, pix, c, acc);
+}
+
+// adjoint of upsample2x_kernel (bilinear x2, align_corners = False): dx += U^T dy, gathered per input pixel
+__global__ void upsample2x_backward_kernel(FMap dy, FMap dx) {
+  const int chunks = dx.C / 8;
+  const long npix = (long)dx.H * dx.W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * chunks * dx.N) return;
+  const int c = (int)(i % chunks) * 8;
+  const long t = i / chunks;
+  const long pix = t % npix;
+  const int n = (int)(t / npix);
+  const int iy = (int)(pix / dx.W), ix = (int)(pix % dx.W);
+  float acc[8];
+  load8(dx, n, pix, c, acc);
+  // output row oy samples source coordinate sy = (oy + 0.5)/2 - 0.5 clamped to >= 0, rows y0 = floor(sy), y1 = min(y0+1, H-1)
+  for (int oy = 2 * iy - 2; oy <= 2 * iy + 2; ++oy) {
+    if (oy < 0 || oy >= dy.H) continue;
+    float sy = (oy + 0.5f) * 0.5f - 0.5f;
+    if (sy < 0.f) sy = 0.f;
+    const int y0 = (int)sy, y1 = min(y0 + 1, dx.H - 1);
+    const float ly = sy - y0;
+    const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+    if (wy == 0.f) continue;
+    for (int ox = 2 * ix - 2; ox <= 2 * ix + 2; ++ox) {
+      if (ox < 0 || ox >= dy.W) continue;
+      float sx = (ox + 0.5f) * 0.5f - 0.5f;
+      if (sx < 0.f) sx = 0.f;
+      const int x0 = (int)sx, x1 = min(x0 + 1, dx.W - 1);
+      const float lx = sx - x0;
+      const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+      if (wx == 0.f) continue;
+      float g[8];
+      load8(dy, n, (long)oy * dy.W + ox, c, g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += wy * wx * g[j];
+    }
+  }
+  store8(dx, n, pix, c, acc);
+}
+
 }  // namespace
 
 extern "C" int tdvc_act_backward(const tdvc_fmap* g, const tdvc_fmap* y, const tdvc_fmap* res, int act, float slope, const tdvc_fmap* out, void* stream) {
@@ -124,4 +358,73 @@ extern "C" int tdvc_bias_grad(const tdvc_fmap* g, int nvalid, const int32_t* dst
   hipLaunchKernelGGL(channel_sum_wide_kernel, dim3(nblocks, g->N, (g->C + 255) / 256), dim3(256), 0, ST(stream), to_dev(*g), work, nblocks);
   hipLaunchKernelGGL(reduce_rows_kernel, dim3((nvalid + 255) / 256), dim3(256), 0, ST(stream), work, g->N * nblocks, g->C, nvalid, dst_index, scale, db);
   return tdvc_launch_status("tdvc_bias_grad");
+}
+
+extern "C" int tdvc_copy_cast(const tdvc_fmap* src, const tdvc_fmap* dst, void* stream) {
+  TDVC_CHECK(src && dst && fmap_any(*src) && fmap_any(*dst) && same_geom(*src, *dst) && dst->C >= src->C && (src->dtype == TDVC_F32 || (src->C % 8) == 0),
+             "tdvc_copy_cast: bad arguments");
+  const long total = (long)dst->N * dst->H * dst->W * ((dst->C + 7) / 8);
+  hipLaunchKernelGGL(copy_cast_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*src), to_dev(*dst));
+  return tdvc_launch_status("tdvc_copy_cast");
+}
+
+extern "C" int tdvc_clamp01_backward(const tdvc_fmap* g, const tdvc_fmap* y, void* stream) {
+  TDVC_CHECK(g && y && fmap_any(*g) && fmap_any(*y) && same_geom(*g, *y) && y->C >= g->C && (g->C % 8) == 0, "tdvc_clamp01_backward: bad arguments");
+  const long total = (long)g->N * g->H * g->W * (g->C / 8);
+  hipLaunchKernelGGL(clamp01_backward_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*g), to_dev(*y));
+  return tdvc_launch_status("tdvc_clamp01_backward");
+}
+
+extern "C" int64_t tdvc_gate_backward_work_floats(int N, int C_) { return (int64_t)N * 64 * C_; }
+
+extern "C" int tdvc_gate_backward(const tdvc_fmap* g, const tdvc_fmap* a, const float* gate, const tdvc_fmap* da, float* dgate, float* work,
+                                  int64_t work_floats, void* stream) {
+  TDVC_CHECK(g && a && gate && dgate && work && fmap_any(*g) && fmap_any(*a) && same_geom(*g, *a) && a->C == g->C && (g->C % 8) == 0 && g->C <= 256,
+             "tdvc_gate_backward: bad arguments");
+  if (da) TDVC_CHECK(fmap_any(*da) && same_geom(*g, *da) && da->C == g->C, "tdvc_gate_backward: bad da");
+  TDVC_CHECK(work_floats >= tdvc_gate_backward_work_floats(g->N, g->C), "tdvc_gate_backward: workspace too small");
+  const int nblocks = 64;
+  hipLaunchKernelGGL(gate_backward_kernel, dim3(nblocks, g->N), dim3(256), 0, ST(stream), to_dev(*g), to_dev(*a), gate, da ? to_dev(*da) : null_fmap(), work, nblocks);
+  hipLaunchKernelGGL(reduce_groups_kernel, dim3((g->N * g->C + 255) / 256), dim3(256), 0, ST(stream), work, g->N, nblocks, g->C, dgate);
+  return tdvc_launch_status("tdvc_gate_backward");
+}
+
+extern "C" int tdvc_se_gate_backward(const float* partial, int nblocks, float inv_count, int N, int C_, int Cmid, const float* w1, const float* b1,
+                                     const float* w2, const float* b2, const float* gate, const float* dgate, float scale, float* dmean,
+                                     float* dw1, float* db1, float* dw2, float* db2, void* stream) {
+  TDVC_CHECK(partial && w1 && b1 && w2 && b2 && gate && dgate && dmean && dw1 && db1 && dw2 && db2 && C_ <= 256 && Cmid <= 32 && N >= 1,
+             "tdvc_se_gate_backward: bad arguments");
+  hipLaunchKernelGGL(se_gate_backward_kernel, dim3(1), dim3(1024), 0, ST(stream), partial, nblocks, inv_count, N, C_, Cmid, w1, b1, w2, b2, gate, dgate,
+                     scale, dmean, dw1, db1, dw2, db2);
+  return tdvc_launch_status("tdvc_se_gate_backward");
+}
+
+extern "C" int tdvc_bcast_channel_add(const tdvc_fmap* dx, const float* v, float scale, void* stream) {
+  TDVC_CHECK(dx && v && fmap_any(*dx) && (dx->C % 8) == 0, "tdvc_bcast_channel_add: bad arguments");
+  const long total = (long)dx->N * dx->H * dx->W * (dx->C / 8);
+  hipLaunchKernelGGL(bcast_channel_add_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*dx), v, scale);
+  return tdvc_launch_status("tdvc_bcast_channel_add");
+}
+
+extern "C" int tdvc_add_flow_backward(const tdvc_fmap* doff, const tdvc_fmap* dflow, void* stream) {
+  TDVC_CHECK(doff && dflow && fmap_ok16(*doff) && fmap_ok32(*dflow) && dflow->C >= 2 && same_geom(*doff, *dflow), "tdvc_add_flow_backward: bad arguments");
+  const long total = (long)doff->N * doff->H * doff->W;
+  hipLaunchKernelGGL(add_flow_backward_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*doff), to_dev(*dflow));
+  return tdvc_launch_status("tdvc_add_flow_backward");
+}
+
+extern "C" int tdvc_bcast_add_act_backward(const tdvc_fmap* dx, const tdvc_fmap* x, const tdvc_fmap* db, float slope, void* stream) {
+  TDVC_CHECK(dx && x && db && fmap_ok16(*dx) && fmap_ok16(*x) && fmap_ok16(*db) && same_geom(*dx, *x) && same_geom(*dx, *db) && dx->C == x->C &&
+                 (dx->C % db->C) == 0, "tdvc_bcast_add_act_backward: bad arguments");
+  const long total = (long)dx->N * dx->H * dx->W * (db->C / 8);
+  hipLaunchKernelGGL(bcast_add_act_backward_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*dx), to_dev(*x), to_dev(*db), slope);
+  return tdvc_launch_status("tdvc_bcast_add_act_backward");
+}
+
+extern "C" int tdvc_upsample2x_backward(const tdvc_fmap* dy, const tdvc_fmap* dx, void* stream) {
+  TDVC_CHECK(dy && dx && fmap_ok16(*dy) && fmap_ok16(*dx) && dy->H == 2 * dx->H && dy->W == 2 * dx->W && dy->C == dx->C && dy->N == dx->N,
+             "tdvc_upsample2x_backward: bad arguments");
+  const long total = (long)dx->N * dx->H * dx->W * (dx->C / 8);
+  hipLaunchKernelGGL(upsample2x_backward_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*dy), to_dev(*dx));
+  return tdvc_launch_status("tdvc_upsample2x_backward");
 }

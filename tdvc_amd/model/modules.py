@@ -70,7 +70,8 @@ class SELayer(nn.Module, PackCache):
             c, m = self.channels, self.conv1.conv.out_channels
             f = lambda t: t.detach().float().contiguous()
             return ops.SEParams(f(self.conv1.conv.weight.view(m, c)), f(self.conv1.conv.bias),
-                                f(self.conv2.conv.weight.view(c, m)), f(self.conv2.conv.bias), c, m)
+                                f(self.conv2.conv.weight.view(c, m)), f(self.conv2.conv.bias), c, m,
+                                params=(self.conv1.conv.weight, self.conv1.conv.bias, self.conv2.conv.weight, self.conv2.conv.bias))
         return self._pk("se", build)
 
     def gate(self, x: FM) -> torch.Tensor:
@@ -323,7 +324,8 @@ class LoopFilter(nn.Module, PackCache):
         self._slices("bs", l1.spatial_conv3d, bf, s)
         tm = ops.conv(s.ch(0, 192), pk_conv(self, "bt", l1.temporal_conv3d))
         ops.bcast_add_act(s, tm, 4, 0.1)
-        o = bf                                                                   # reuse
+        # inference re-uses `bf` for the block output; under the tape `bf` is still needed by the backward of `bs`
+        o = bf if ops.TAPE is None else FM.empty(B, H, W, 256, device=dev)
         self._slices("b3", l1.conv3, s, o, res_buf=a)
         f = ops.conv(o, pk_conv(self, "ff", self.feat_fusion), **lr)
         return self.attn.run(f, out=out, res=xt.ch(192, 64))

@@ -24,6 +24,16 @@ def _stream():
 
 # optional per-launch event trace (bench.py roofline leg): list of dicts, or None
 PROFILE = None
+# active autograd tape (tdvc_amd/autograd.py) or None: differentiable ops record their backward closure on it
+TAPE = None
+_IN_BACKWARD = False      # set by Tape.backward(): ops called from backward closures are not recorded
+
+
+def _rec(name, *args):
+    """record a differentiable op on the active tape (no-op outside `autograd.record()`)"""
+    if TAPE is not None and not _IN_BACKWARD:
+        from . import autograd
+        getattr(autograd, "record_" + name)(TAPE, *args)
 
 
 def pad8(c: int) -> int:
@@ -129,6 +139,8 @@ class PackedConv:
     tables: convpack.PackTables | None = None
     orig: dict | None = None               # geometry of the ORIGINAL conv: stride, pad, taps, cin_perm, kh, kw
     dgrad: "PackedConv | None" = None      # lazily built data-gradient conv (ops.conv_dgrad)
+    param_w: torch.Tensor | None = None    # the nn.Parameters that own wsrc / bsrc (gradient accumulators live on them)
+    param_b: torch.Tensor | None = None
 
     def repack(self):
         """re-pack from the (updated) fp32 parameters: one kernel launch, plus the bias gather"""
@@ -188,7 +200,8 @@ def _pick_ck(cin, cout, kh, kw, stride, pad):
 
 def pack_conv(weight: torch.Tensor, bias: torch.Tensor | None, stride=1, pad=0, cin_pad: int | None = None,
               taps=None, shuffle=False, cin_perm=None, device="cuda", ck=None, allow_s2d=True,
-              layout: convpack.WeightLayout | None = None) -> PackedConv:
+              layout: convpack.WeightLayout | None = None, param_w: torch.Tensor | None = None,
+              param_b: torch.Tensor | None = None) -> PackedConv:
     """weight (cout, cin, kh, kw) fp32 (moved to `device` if it is not there; an nn.Parameter on the device is
     referenced, not copied, so `PackedConv.repack()` sees optimizer updates).  `taps`: list of (dy,dx) to keep
     (masked convs); `shuffle`: rows permuted for the PixelShuffle(2) store; `cin_perm`: index list applied to
@@ -223,7 +236,9 @@ def pack_conv(weight: torch.Tensor, bias: torch.Tensor | None, stride=1, pad=0, 
     bp = torch.zeros(_cout_pad(cout), dtype=torch.float32, device=dev)
     pc = PackedConv(_pack_from_tables(wsrc, tb), bp, cout, cin, tb.kh, tb.kw, k_stride, k_pad, tb.ck, tb.taps, shuffle, cin_real,
                     s2d=s2d, flops_per_px=2.0 * cout * cin_real * 9 if s2d else 0.0,
-                    wsrc=wsrc, bsrc=bsrc, layout=layout, tables=tb, orig=orig)
+                    wsrc=wsrc, bsrc=bsrc, layout=layout, tables=tb, orig=orig,
+                    param_w=param_w if param_w is not None else (weight if isinstance(weight, torch.nn.Parameter) else None),
+                    param_b=param_b if param_b is not None else (bias if isinstance(bias, torch.nn.Parameter) else None))
     if bsrc is not None:
         b = bsrc.detach().float()
         bp[:cout] = b[torch.from_numpy(convpack.shuffle_perm(cout)).to(dev)] if shuffle else b
@@ -285,6 +300,7 @@ def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, 
                             bytes=2.0 * x.N * (x.H * x.W * x.C + Ho * Wo * pc.cout * (4 if pc.shuffle else 1) / (4 if pc.shuffle else 1))))
         return ret
     L.check(L.lib().tdvc_conv2d(C.byref(d), _stream()), "conv2d")
+    _rec("conv", x, pc, None if nchw_out is not None else ret, act, slope, res, res2, gdn, aux, square, nchw_out)
     return ret
 
 
@@ -368,6 +384,60 @@ def conv_bgrad(pc: PackedConv, g: FM, db: torch.Tensor, scale=1.0) -> None:
                                _stream()), "bias_grad")
 
 
+def copy_cast(src: FM, dst: FM) -> FM:
+    ds, dd = src.desc(), dst.desc()
+    L.check(L.lib().tdvc_copy_cast(C.byref(ds), C.byref(dd), _stream()), "copy_cast")
+    return dst
+
+
+def clamp01_backward(g: FM, y: FM) -> FM:
+    dg, dy = g.desc(), y.desc()
+    L.check(L.lib().tdvc_clamp01_backward(C.byref(dg), C.byref(dy), _stream()), "clamp01_backward")
+    return g
+
+
+def gate_backward(g: FM, a: FM, gate: torch.Tensor, da: FM | None, dgate: torch.Tensor) -> None:
+    lib = L.lib()
+    nwork = lib.tdvc_gate_backward_work_floats(g.N, g.C)
+    work = torch.empty((nwork,), dtype=torch.float32, device=gate.device)
+    dg, dad = g.desc(), a.desc()
+    dda = da.desc() if da is not None else None
+    L.check(lib.tdvc_gate_backward(C.byref(dg), C.byref(dad), gate.data_ptr(), C.byref(dda) if dda is not None else None, dgate.data_ptr(),
+                                   work.data_ptr(), nwork, _stream()), "gate_backward")
+
+
+def se_gate_backward(p: "SEParams", partial: torch.Tensor, nblocks: int, npix: int, gate: torch.Tensor, dgate: torch.Tensor, scale: float,
+                     grads) -> torch.Tensor:
+    """-> dmean [N][C]; parameter gradients accumulate into `grads` = (dw1, db1, dw2, db2)"""
+    N = gate.shape[0]
+    dmean = torch.empty_like(gate)
+    L.check(L.lib().tdvc_se_gate_backward(partial.data_ptr(), nblocks, 1.0 / npix, N, p.C, p.Cmid, p.w1.data_ptr(), p.b1.data_ptr(),
+                                          p.w2.data_ptr(), p.b2.data_ptr(), gate.data_ptr(), dgate.data_ptr(), scale, dmean.data_ptr(),
+                                          grads[0].data_ptr(), grads[1].data_ptr(), grads[2].data_ptr(), grads[3].data_ptr(), _stream()),
+            "se_gate_backward")
+    return dmean
+
+
+def bcast_channel_add(dx: FM, v: torch.Tensor, scale: float) -> None:
+    d = dx.desc()
+    L.check(L.lib().tdvc_bcast_channel_add(C.byref(d), v.data_ptr(), scale, _stream()), "bcast_channel_add")
+
+
+def add_flow_backward(doff: FM, dflow: FM) -> None:
+    do, df = doff.desc(), dflow.desc()
+    L.check(L.lib().tdvc_add_flow_backward(C.byref(do), C.byref(df), _stream()), "add_flow_backward")
+
+
+def bcast_add_act_backward(dx: FM, x: FM, db: FM, slope: float) -> None:
+    d1, d2, d3 = dx.desc(), x.desc(), db.desc()
+    L.check(L.lib().tdvc_bcast_add_act_backward(C.byref(d1), C.byref(d2), C.byref(d3), slope, _stream()), "bcast_add_act_backward")
+
+
+def upsample2x_backward(dy: FM, dx: FM) -> None:
+    d1, d2 = dy.desc(), dx.desc()
+    L.check(L.lib().tdvc_upsample2x_backward(C.byref(d1), C.byref(d2), _stream()), "upsample2x_backward")
+
+
 def dcn_fused(x: FM, om: FM, pc: PackedConv, out: FM, groups=8, act=ACT_NONE, slope=0.0, round16=True) -> FM:
     d = L.DcnDesc()
     d.x, d.om, d.y = x.desc(), om.desc(), out.desc()
@@ -386,17 +456,20 @@ def scale_act_res(a: FM, out: FM, gate: torch.Tensor | None = None, act=ACT_NONE
     L.check(L.lib().tdvc_scale_act_res(C.byref(da), gate.data_ptr() if gate is not None else None, act, slope,
                                        C.byref(dr) if dr is not None else None, res_sign, C.byref(dy),
                                        C.byref(d2) if d2 is not None else None, _stream()), "scale_act_res")
+    _rec("scale_act_res", a, out, gate, act, slope, res, res_sign, out2)
     return out
 
 
 def add_flow(off: FM, flow: FM):
     do, df = off.desc(), flow.desc()
     L.check(L.lib().tdvc_add_flow(C.byref(do), C.byref(df), _stream()), "add_flow")
+    _rec("add_flow", off, flow)
 
 
 def bcast_add_act(x: FM, b: FM, T: int, slope: float):
     dx, db = x.desc(), b.desc()
     L.check(L.lib().tdvc_bcast_add_act(C.byref(dx), C.byref(db), T, slope, _stream()), "bcast_add_act")
+    _rec("bcast_add_act", x, b, slope)
 
 
 @dataclass
@@ -407,6 +480,7 @@ class SEParams:
     b2: torch.Tensor
     C: int
     Cmid: int
+    params: tuple = ()       # the four nn.Parameters (gradient accumulators), same storage as w1 / b1 / w2 / b2
 
 
 def se_gate(x: FM, p: SEParams) -> torch.Tensor:
@@ -420,6 +494,7 @@ def se_gate(x: FM, p: SEParams) -> torch.Tensor:
     L.check(lib.tdvc_channel_sum(C.byref(dx), partial.data_ptr(), nblocks, _stream()), "channel_sum")
     L.check(lib.tdvc_se_gate(partial.data_ptr(), nblocks, 1.0 / npix, x.N, p.C, p.Cmid, p.w1.data_ptr(),
                              p.b1.data_ptr(), p.w2.data_ptr(), p.b2.data_ptr(), gate.data_ptr(), _stream()), "se_gate")
+    _rec("se_gate", x, p, partial, nblocks, gate)
     return gate
 
 
@@ -429,6 +504,7 @@ def upsample2x(x: FM, out: FM | None = None) -> FM:
         out = FM.empty(x.N, 2 * x.H, 2 * x.W, x.C, device=x.t.device)
     dx, dy = x.desc(), out.desc()
     L.check(L.lib().tdvc_upsample2x(C.byref(dx), C.byref(dy), _stream()), "upsample2x")
+    _rec("upsample2x", x, out)
     return out
 
 

@@ -1,0 +1,115 @@
+"""Tape-based backward (tdvc_amd/autograd.py) vs torch autograd through the fp32 CPU oracle modules
+(same state-dict keys, same filler weights, same inputs).  Gradients are compared by relative L2 error per
+tensor: activations are fp16 on the device, so element-wise agreement is ~1e-2 of the tensor's scale."""
+import pytest
+import torch
+
+from util import fm_to_cpu, randn, rnd16, to_fm
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(got, ref):
+    return float((got.double() - ref.double()).norm() / (ref.double().norm() + 1e-12))
+
+
+def _pair(dev_cls, ref_cls, *args, seed=0):
+    from tdvc_amd import synth
+    ref = ref_cls(*args)
+    synth.fill_parameters(ref)
+    dev = dev_cls(*args)
+    dev.load_state_dict(ref.state_dict())
+    return dev.cuda(), ref
+
+
+def _check_param_grads(dev, ref, report, tol, what):
+    worst = 0.0
+    for (k, p), (k2, q) in zip(dev.named_parameters(), ref.named_parameters()):
+        assert k == k2
+        assert p.grad is not None, f"{what}: no gradient for {k}"
+        r = _rel(p.grad.cpu(), q.grad)
+        worst = max(worst, r)
+        assert r < tol, f"{what}: grad {k} rel err {r:.3e} (|ref| {float(q.grad.norm()):.3e})"
+    report(f"{what}: worst parameter-gradient rel L2 err {worst:.3e}")
+
+
+def test_feaextra_backward(report):
+    from oracle.tdvc_ref import blocks as ob
+    from tdvc_amd import autograd, ops
+    from tdvc_amd.model import modules as dm
+    dev, ref = _pair(dm.FeaExtra, ob.FeaExtra, 2)
+    x = rnd16(torch.rand(2, 3, 32, 48, generator=torch.Generator().manual_seed(1)))
+    wgt = randn(2, 64, 32, 48, seed=2)
+    # oracle
+    y = ref(x)
+    (y * wgt).sum().backward()
+    # device
+    with autograd.record() as tape:
+        img8 = to_fm(x, ops, Cpad=8)
+        tape.mark_input(img8)
+        out = ops.FM.empty(2, 32, 48, 64)
+        dev.run(img8, out)
+        ops.copy_cast(to_fm(wgt, ops), tape.grad(out))       # seed dL/dout
+        tape.backward()
+    assert _rel(fm_to_cpu(out), y.detach()) < 3e-3
+    _check_param_grads(dev, ref, report, 2e-2, "FeaExtra")
+
+
+def test_se_upsample_flow_chain_backward(report):
+    """conv -> SE scaling (+ residual) -> bilinear x2 -> conv (fp32 out + fp32 residual): gate, pooling and resampling adjoints"""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from oracle.tdvc_ref import blocks as ob
+    from tdvc_amd import autograd, ops, synth
+    from tdvc_amd.model import modules as dm
+
+    class RefNet(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1 = nn.Conv2d(64, 64, 3, 1, 1)
+            self.attn = ob.SELayer(64)
+            self.c2 = nn.Conv2d(64, 2, 3, 1, 1)
+
+        def forward(self, x, r, up):
+            t = F.leaky_relu(self.c1(x), 0.1)
+            t = self.attn(t) + r
+            t = F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False)
+            return self.c2(t) + up
+
+    class DevNet(nn.Module, dm.PackCache):
+        def __init__(self):
+            super().__init__()
+            self.c1 = nn.Conv2d(64, 64, 3, 1, 1)
+            self.attn = dm.SELayer(64)
+            self.c2 = nn.Conv2d(64, 2, 3, 1, 1)
+
+        def run(self, x, r, up):
+            t = ops.conv(x, dm.pk_conv(self, "c1", self.c1), act=ops.ACT_LRELU, slope=0.1)
+            t = self.attn.run(t, res=r)
+            t = ops.upsample2x(t)
+            return ops.conv(t, dm.pk_conv(self, "c2", self.c2), res=up, out_dtype=torch.float32)
+
+    ref = RefNet()
+    synth.fill_parameters(ref)
+    dev = DevNet()
+    dev.load_state_dict(ref.state_dict())
+    dev = dev.cuda()
+    x = rnd16(randn(2, 64, 20, 28, seed=4)).requires_grad_()
+    r = rnd16(randn(2, 64, 20, 28, seed=5)).requires_grad_()
+    up = randn(2, 2, 40, 56, seed=6).requires_grad_()
+    wgt = randn(2, 2, 40, 56, seed=7)
+    y = ref(x, r, up)
+    (y * wgt).sum().backward()
+    with autograd.record() as tape:
+        xf, rf = to_fm(x.detach(), ops), to_fm(r.detach(), ops)
+        upf = to_fm(up.detach(), ops, Cpad=2, dtype=torch.float32)
+        out = dev.run(xf, rf, upf)
+        ops.copy_cast(to_fm(wgt, ops, Cpad=2, dtype=torch.float32), tape.grad(out))
+        tape.backward()
+        gx, gr, gup = fm_to_cpu(tape.grad(xf)), fm_to_cpu(tape.grad(rf)), fm_to_cpu(tape.grad(upf))
+    assert _rel(fm_to_cpu(out), y.detach()) < 3e-3
+    for name, got, want in (("dx", gx, x.grad), ("dres", gr, r.grad), ("dup", gup, up.grad)):
+        e = _rel(got, want)
+        report(f"SE/upsample chain {name}: rel L2 err {e:.3e}")
+        assert e < 2e-2, (name, e)
+    _check_param_grads(dev, ref, report, 2e-2, "SE/upsample chain")
