@@ -157,6 +157,14 @@ def record_se_gate(tape: Tape, x: FM, p, partial, nblocks, gate):
     tape.add(bwd)
 
 
+def record_clone(tape: Tape, x: FM, out: FM):
+    def bwd():
+        if tape.needs_grad(x):
+            accumulate(tape.grad(x), tape.grad(out))
+
+    tape.add(bwd)
+
+
 def record_add_flow(tape: Tape, off: FM, flow: FM):
     tape.add(lambda: ops.add_flow_backward(tape.grad(off), tape.grad(flow)))
 

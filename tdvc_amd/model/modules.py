@@ -39,10 +39,11 @@ def pk_conv(owner: PackCache, name: str, conv: nn.Module, **kw) -> ops.PackedCon
         if w.dim() == 5:                       # Conv3d holders
             co, ci, kt, kh, kw_ = w.shape
             if kt == 1:                        # (1,3,3): a 2-D conv applied to every frame (a view of the parameter)
-                return ops.pack_conv(w.view(co, ci, kh, kw_), conv.bias, stride=1, pad=conv.padding[-1], device=w.device, **kw)
+                return ops.pack_conv(w.view(co, ci, kh, kw_), conv.bias, stride=1, pad=conv.padding[-1], device=w.device,
+                                     param_w=conv.weight, param_b=conv.bias, **kw)
             # (3,1,1) stride 3: 1x1 conv over T*C channels, t-major, gathered straight from the 5-D parameter
             return ops.pack_conv(w, conv.bias, stride=1, pad=0, device=w.device,
-                                 layout=ops.convpack.WeightLayout.conv3d_temporal(co, ci, kt), **kw)
+                                 layout=ops.convpack.WeightLayout.conv3d_temporal(co, ci, kt), param_w=conv.weight, param_b=conv.bias, **kw)
         return ops.pack_conv(w, conv.bias, stride=conv.stride[0], pad=conv.padding[0], device=w.device, **kw)
     return owner._pk(name, build)
 
@@ -229,6 +230,8 @@ class OffsetGen(nn.Module, PackCache):
                 up_o1 = FM.empty(B, up.H, up.W, 128, device=dev)      # [upsampled_offset | offset1]
                 ops.conv(up, pk_conv(self, "upc", self.upsample_conv), out=up_o1.ch(0, 64))
         flow = self.spynet.run(cur32, ref32)
+        if ops.TAPE is not None:
+            off = ops.clone(off)      # keep the fusion conv's own output (LeakyReLU sign) for the backward pass
         ops.add_flow(off, flow)
         e = ops.conv(off, pk_conv(self, "ff_", self.feat_fusion_))
         return self.attn.run(e)
@@ -323,6 +326,8 @@ class LoopFilter(nn.Module, PackCache):
         s = FM.empty(B, H, W, 256, device=dev)
         self._slices("bs", l1.spatial_conv3d, bf, s)
         tm = ops.conv(s.ch(0, 192), pk_conv(self, "bt", l1.temporal_conv3d))
+        if ops.TAPE is not None:
+            s = ops.clone(s)          # `s` itself is the temporal conv's input: keep it for the backward pass
         ops.bcast_add_act(s, tm, 4, 0.1)
         # inference re-uses `bf` for the block output; under the tape `bf` is still needed by the backward of `bs`
         o = bf if ops.TAPE is None else FM.empty(B, H, W, 256, device=dev)

@@ -460,6 +460,14 @@ def scale_act_res(a: FM, out: FM, gate: torch.Tensor | None = None, act=ACT_NONE
     return out
 
 
+def clone(x: FM) -> FM:
+    """a recorded copy: the in-place kernels below run on it under the tape, so that the producer of `x` still finds
+    its own output (activation sign, weight-gradient operand) in the backward pass"""
+    out = copy_cast(x, FM.empty(x.N, x.H, x.W, x.C, dtype=x.t.dtype, device=x.t.device))
+    _rec("clone", x, out)
+    return out
+
+
 def add_flow(off: FM, flow: FM):
     do, df = off.desc(), flow.desc()
     L.check(L.lib().tdvc_add_flow(C.byref(do), C.byref(df), _stream()), "add_flow")

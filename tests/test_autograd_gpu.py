@@ -113,3 +113,33 @@ def test_se_upsample_flow_chain_backward(report):
         report(f"SE/upsample chain {name}: rel L2 err {e:.3e}")
         assert e < 2e-2, (name, e)
     _check_param_grads(dev, ref, report, 2e-2, "SE/upsample chain")
+
+
+def test_loopfilter_backward(report):
+    """multi-frame fusion: convs over frame slices, the temporal (3,1,1) conv broadcast over T, 1x1 fusion, SE"""
+    from oracle.tdvc_ref import blocks as ob
+    from tdvc_amd import autograd, ops
+    from tdvc_amd.model import modules as dm
+    dev, ref = _pair(dm.LoopFilter, ob.LoopFilter)
+    B, H, W = 2, 24, 32
+    g = torch.Generator().manual_seed(11)
+    pred = rnd16(torch.randn(B, 64, H, W, generator=g) * 0.5).requires_grad_()
+    refs = rnd16(torch.rand(B, 4, 3, H, W, generator=g))
+    wgt = randn(B, 64, H, W, seed=12)
+    y = ref(pred, refs)
+    (y * wgt).sum().backward()
+    with autograd.record() as tape:
+        xt = ops.FM.empty(B, H, W, 256)
+        ops.copy_cast(to_fm(pred.detach(), ops), xt.ch(192, 64))
+        refs8 = to_fm(refs.reshape(B * 4, 3, H, W), ops, Cpad=8)
+        tape.mark_input(refs8)
+        out = ops.FM.empty(B, H, W, 64)
+        dev.run(xt, refs8, out)
+        ops.copy_cast(to_fm(wgt, ops), tape.grad(out))
+        tape.backward()
+        gpred = fm_to_cpu(tape.grad(xt.ch(192, 64)))
+    assert _rel(fm_to_cpu(out), y.detach()) < 3e-3
+    e = _rel(gpred, pred.grad)
+    report(f"LoopFilter dpred: rel L2 err {e:.3e}")
+    assert e < 2e-2
+    _check_param_grads(dev, ref, report, 3e-2, "LoopFilter")
