@@ -313,6 +313,12 @@ int tdvc_bcast_add_act_backward(const tdvc_fmap* dx, const tdvc_fmap* x, const t
 /* adjoint of tdvc_upsample2x: dx += U^T dy. */
 int tdvc_upsample2x_backward(const tdvc_fmap* dy, const tdvc_fmap* dx, void* stream);
 
+/* backward of tdvc_spynet_level_input (flownet.py:82-140): dflow_up += flow channels of dcat8 + the warp gradient
+ * (grid_sample bilinear / border / align_corners=True w.r.t. the flow), then dflow_lo += 2 * U^T dflow_up.  The images
+ * need no gradient.  dflow_lo may be NULL (coarsest level). */
+int tdvc_spynet_level_input_backward(const tdvc_fmap* supp, const tdvc_fmap* flow_up, const tdvc_fmap* dcat8, const tdvc_fmap* dflow_up,
+                                     const tdvc_fmap* dflow_lo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

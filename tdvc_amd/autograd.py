@@ -179,3 +179,8 @@ def record_upsample2x(tape: Tape, x: FM, out: FM):
             ops.upsample2x_backward(tape.grad(out), tape.grad(x))
 
     tape.add(bwd)
+
+
+def record_spynet_level_input(tape: Tape, supp: FM, flow_lo, flow_up: FM, cat8: FM):
+    tape.add(lambda: ops.spynet_level_input_backward(supp, flow_up, tape.grad(cat8), tape.grad(flow_up),
+                                                     tape.grad(flow_lo) if flow_lo is not None else None))

@@ -328,6 +328,86 @@ __global__ void upsample2x_backward_kernel(FMap dy, FMap dx) {
   store8(dx, n, pix, c, acc);
 }
 
+// Backward of spynet_level_input_kernel, stage 1 (per full-resolution pixel): total gradient of the up-sampled flow
+//   dflow_up <- dflow_up (conv residual) + dcat8[6:8] (flow channels of the level input) + warp gradient
+// The warp is grid_sample(bilinear, border, align_corners=True): d/d(ix) of the bilinear sample, zero where the
+// sampling position was clamped to the border (torch's clip_coordinates_set_grad).
+__global__ void spynet_warp_backward_kernel(FMap supp, FMap flow_up, FMap dcat8, FMap dflow_up) {
+  const int H = supp.H, W = supp.W;
+  const long npix = (long)H * W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * supp.N) return;
+  const int n = (int)(i / npix);
+  const long pix = i % npix;
+  const int y = (int)(pix / W), x = (int)(pix % W);
+  const float* fu = reinterpret_cast<const float*>(flow_up.p) + (long)n * flow_up.sn + pix * flow_up.sp;
+  const float fx = fu[0], fy = fu[1];
+  const float gx = (float)x + fx, gy = (float)y + fy;
+  const float wm = (float)(W - 1 > 1 ? W - 1 : 1), hm = (float)(H - 1 > 1 ? H - 1 : 1);
+  const float nx = 2.0f * gx / wm - 1.0f, ny = 2.0f * gy / hm - 1.0f;
+  float ix = ((nx + 1.f) / 2.f) * (float)(W - 1), iy = ((ny + 1.f) / 2.f) * (float)(H - 1);
+  const float mx = (ix >= 0.f && ix <= (float)(W - 1)) ? (float)(W - 1) / wm : 0.f;      // d ix / d fx (0 where clamped)
+  const float my = (iy >= 0.f && iy <= (float)(H - 1)) ? (float)(H - 1) / hm : 0.f;
+  ix = fminf((float)(W - 1), fmaxf(ix, 0.f));
+  iy = fminf((float)(H - 1), fmaxf(iy, 0.f));
+  const int ix0 = (int)floorf(ix), iy0 = (int)floorf(iy), ix1 = ix0 + 1, iy1 = iy0 + 1;
+  const bool x0ok = ix0 >= 0 && ix0 < W, x1ok = ix1 >= 0 && ix1 < W, y0ok = iy0 >= 0 && iy0 < H, y1ok = iy1 >= 0 && iy1 < H;
+  const float* sp = reinterpret_cast<const float*>(supp.p) + (long)n * supp.sn;
+  float dc[8];
+  load8(dcat8, n, pix, 0, dc);
+  float gix = 0.f, giy = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float nw = (y0ok && x0ok) ? sp[((long)iy0 * W + ix0) * supp.sp + c] : 0.f;
+    const float ne = (y0ok && x1ok) ? sp[((long)iy0 * W + ix1) * supp.sp + c] : 0.f;
+    const float sw = (y1ok && x0ok) ? sp[((long)iy1 * W + ix0) * supp.sp + c] : 0.f;
+    const float se = (y1ok && x1ok) ? sp[((long)iy1 * W + ix1) * supp.sp + c] : 0.f;
+    const float g = dc[3 + c];
+    gix += g * ((ne - nw) * ((float)iy1 - iy) + (se - sw) * (iy - (float)iy0));
+    giy += g * ((sw - nw) * ((float)ix1 - ix) + (se - ne) * (ix - (float)ix0));
+  }
+  float* df = reinterpret_cast<float*>(dflow_up.p) + (long)n * dflow_up.sn + pix * dflow_up.sp;
+  df[0] += dc[6] + mx * gix;
+  df[1] += dc[7] + my * giy;
+}
+
+// stage 2 (per half-resolution pixel): dflow_lo += 2 * U^T dflow_up, U = bilinear x2 with align_corners = True
+__global__ void upsample_ac_backward_kernel(FMap dhi, FMap dlo) {
+  const int H = dhi.H, W = dhi.W, h2 = dlo.H, w2 = dlo.W;
+  const long npix = (long)h2 * w2;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * dlo.N) return;
+  const int n = (int)(i / npix);
+  const long pix = i % npix;
+  const int Y = (int)(pix / w2), X = (int)(pix % w2);
+  const float ry = (H > 1) ? (float)(h2 - 1) / (float)(H - 1) : 0.f;
+  const float rx = (W > 1) ? (float)(w2 - 1) / (float)(W - 1) : 0.f;
+  const int ylo = ry > 0.f ? max(0, (int)floorf((Y - 1) / ry)) : 0, yhi = ry > 0.f ? min(H - 1, (int)ceilf((Y + 1) / ry)) : H - 1;
+  const int xlo = rx > 0.f ? max(0, (int)floorf((X - 1) / rx)) : 0, xhi = rx > 0.f ? min(W - 1, (int)ceilf((X + 1) / rx)) : W - 1;
+  const float* hp = reinterpret_cast<const float*>(dhi.p) + (long)n * dhi.sn;
+  float sx = 0.f, sy_ = 0.f;
+  for (int y = ylo; y <= yhi; ++y) {
+    const float sy = ry * y;
+    const int y0 = (int)sy, y1 = y0 + (y0 < h2 - 1);
+    const float ly1 = sy - y0;
+    const float wy = (y0 == Y ? 1.f - ly1 : 0.f) + (y1 == Y ? ly1 : 0.f);
+    if (wy == 0.f) continue;
+    for (int x = xlo; x <= xhi; ++x) {
+      const float sxx = rx * x;
+      const int x0 = (int)sxx, x1 = x0 + (x0 < w2 - 1);
+      const float lx1 = sxx - x0;
+      const float wx = (x0 == X ? 1.f - lx1 : 0.f) + (x1 == X ? lx1 : 0.f);
+      if (wx == 0.f) continue;
+      const float* g = hp + ((long)y * W + x) * dhi.sp;
+      sx += wy * wx * g[0];
+      sy_ += wy * wx * g[1];
+    }
+  }
+  float* lp = reinterpret_cast<float*>(dlo.p) + (long)n * dlo.sn + pix * dlo.sp;
+  lp[0] += 2.f * sx;
+  lp[1] += 2.f * sy_;
+}
+
 }  // namespace
 
 extern "C" int tdvc_act_backward(const tdvc_fmap* g, const tdvc_fmap* y, const tdvc_fmap* res, int act, float slope, const tdvc_fmap* out, void* stream) {
@@ -427,4 +507,19 @@ extern "C" int tdvc_upsample2x_backward(const tdvc_fmap* dy, const tdvc_fmap* dx
   const long total = (long)dx->N * dx->H * dx->W * (dx->C / 8);
   hipLaunchKernelGGL(upsample2x_backward_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*dy), to_dev(*dx));
   return tdvc_launch_status("tdvc_upsample2x_backward");
+}
+
+extern "C" int tdvc_spynet_level_input_backward(const tdvc_fmap* supp, const tdvc_fmap* flow_up, const tdvc_fmap* dcat8, const tdvc_fmap* dflow_up,
+                                                const tdvc_fmap* dflow_lo, void* stream) {
+  TDVC_CHECK(supp && flow_up && dcat8 && dflow_up && fmap_ok32(*supp) && supp->C >= 3 && fmap_ok32(*flow_up) && flow_up->C >= 2 &&
+                 fmap_ok32(*dflow_up) && dflow_up->C >= 2 && fmap_ok16(*dcat8) && dcat8->C == 8 && same_geom(*supp, *flow_up) &&
+                 same_geom(*supp, *dcat8) && same_geom(*supp, *dflow_up), "tdvc_spynet_level_input_backward: bad arguments");
+  const long total = (long)supp->N * supp->H * supp->W;
+  hipLaunchKernelGGL(spynet_warp_backward_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*supp), to_dev(*flow_up), to_dev(*dcat8), to_dev(*dflow_up));
+  if (dflow_lo) {
+    TDVC_CHECK(fmap_ok32(*dflow_lo) && dflow_lo->C >= 2 && dflow_lo->N == supp->N, "tdvc_spynet_level_input_backward: bad dflow_lo");
+    const long tl = (long)dflow_lo->N * dflow_lo->H * dflow_lo->W;
+    hipLaunchKernelGGL(upsample_ac_backward_kernel, grid1d(tl), dim3(EW_BLOCK), 0, ST(stream), to_dev(*dflow_up), to_dev(*dflow_lo));
+  }
+  return tdvc_launch_status("tdvc_spynet_level_input_backward");
 }

@@ -528,6 +528,14 @@ def spynet_level_input(ref: FM, supp: FM, flow_lo: FM | None, flow_up: FM, cat8:
     dl = flow_lo.desc() if flow_lo is not None else None
     L.check(L.lib().tdvc_spynet_level_input(C.byref(dr), C.byref(ds), C.byref(dl) if dl is not None else None,
                                             C.byref(du), C.byref(dc), _stream()), "spynet_level_input")
+    _rec("spynet_level_input", supp, flow_lo, flow_up, cat8)
+
+
+def spynet_level_input_backward(supp: FM, flow_up: FM, dcat8: FM, dflow_up: FM, dflow_lo: FM | None) -> None:
+    d1, d2, d3, d4 = supp.desc(), flow_up.desc(), dcat8.desc(), dflow_up.desc()
+    d5 = dflow_lo.desc() if dflow_lo is not None else None
+    L.check(L.lib().tdvc_spynet_level_input_backward(C.byref(d1), C.byref(d2), C.byref(d3), C.byref(d4),
+                                                     C.byref(d5) if d5 is not None else None, _stream()), "spynet_level_input_backward")
 
 
 def resize_bilinear(x: FM, H: int, W: int, chscale: torch.Tensor | None = None) -> FM:
