@@ -319,6 +319,11 @@ int tdvc_upsample2x_backward(const tdvc_fmap* dy, const tdvc_fmap* dx, void* str
 int tdvc_spynet_level_input_backward(const tdvc_fmap* supp, const tdvc_fmap* flow_up, const tdvc_fmap* dcat8, const tdvc_fmap* dflow_up,
                                      const tdvc_fmap* dflow_lo, void* stream);
 
+/* flat fp32 helpers of the DCN backward glue: out = sigmoid(x); g *= s*(1-s); dst += scale*src. */
+int tdvc_sigmoid_f32(const float* x, float* out, int64_t n, void* stream);
+int tdvc_sigmoid_backward_f32(float* g, const float* s, int64_t n, void* stream);
+int tdvc_axpy_f32(float* dst, const float* src, float scale, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

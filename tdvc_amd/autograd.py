@@ -184,3 +184,29 @@ def record_upsample2x(tape: Tape, x: FM, out: FM):
 def record_spynet_level_input(tape: Tape, supp: FM, flow_lo, flow_up: FM, cat8: FM):
     tape.add(lambda: ops.spynet_level_input_backward(supp, flow_up, tape.grad(cat8), tape.grad(flow_up),
                                                      tape.grad(flow_lo) if flow_lo is not None else None))
+
+
+def record_dcn_fused(tape: Tape, x: FM, om: FM, pc, out: FM, groups, act, slope):
+    """DCNv2 backward through the fp32 planar operator (`_ext.dcn_v2_backward`, src/cuda/dcn_v2_cuda.cu:97-216): the fused
+    forward keeps no column buffer, so the operands are converted once here."""
+    weight, bias = pc.param_w, pc.param_b
+
+    def bwd():
+        from .dcn_ext import dcn_v2_backward
+        g = tape.grad(out)
+        if act in (ops.ACT_RELU, ops.ACT_LRELU):
+            g = ops.act_backward(g, out, act, slope)
+        G = groups
+        mask = ops.sigmoid_f32(om.ch(18 * G, 9 * G).to_nchw())
+        gi, goff, gmask, gw, gb = dcn_v2_backward(x.to_nchw(), weight.detach(), bias.detach(), om.ch(0, 18 * G).to_nchw(), mask,
+                                                  g.to_nchw(), 3, 3, 1, 1, 1, 1, 1, 1, G)
+        ops.sigmoid_backward_f32(gmask, mask)
+        if tape.needs_grad(x):
+            accumulate(tape.grad(x), ops.from_nchw(gi))
+        dom = tape.grad(om)
+        accumulate(dom.ch(0, 18 * G), ops.from_nchw(goff))
+        accumulate(dom.ch(18 * G, 9 * G), ops.from_nchw(gmask))
+        ops.axpy_f32(param_grad(weight), gw, tape.inv_scale)
+        ops.axpy_f32(param_grad(bias), gb, tape.inv_scale)
+
+    tape.add(bwd)

@@ -408,6 +408,21 @@ __global__ void upsample_ac_backward_kernel(FMap dhi, FMap dlo) {
   lp[1] += 2.f * sy_;
 }
 
+// out = sigmoid(x) / g *= s * (1 - s) on flat fp32 arrays (DCN modulation mask, dcn_v2_amp.py:226)
+__global__ void sigmoid_f32_kernel(const float* x, float* out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = 1.f / (1.f + __expf(-x[i]));
+}
+__global__ void sigmoid_backward_f32_kernel(float* g, const float* s, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) g[i] *= s[i] * (1.f - s[i]);
+}
+// dst += scale * src on flat fp32 arrays (parameter-gradient accumulation)
+__global__ void axpy_f32_kernel(float* dst, const float* src, float scale, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += scale * src[i];
+}
+
 }  // namespace
 
 extern "C" int tdvc_act_backward(const tdvc_fmap* g, const tdvc_fmap* y, const tdvc_fmap* res, int act, float slope, const tdvc_fmap* out, void* stream) {
@@ -522,4 +537,20 @@ extern "C" int tdvc_spynet_level_input_backward(const tdvc_fmap* supp, const tdv
     hipLaunchKernelGGL(upsample_ac_backward_kernel, grid1d(tl), dim3(EW_BLOCK), 0, ST(stream), to_dev(*dflow_up), to_dev(*dflow_lo));
   }
   return tdvc_launch_status("tdvc_spynet_level_input_backward");
+}
+
+extern "C" int tdvc_sigmoid_f32(const float* x, float* out, int64_t n, void* stream) {
+  TDVC_CHECK(x && out && n >= 0, "tdvc_sigmoid_f32: bad arguments");
+  if (n) hipLaunchKernelGGL(sigmoid_f32_kernel, grid1d(n), dim3(EW_BLOCK), 0, ST(stream), x, out, (long)n);
+  return tdvc_launch_status("tdvc_sigmoid_f32");
+}
+extern "C" int tdvc_sigmoid_backward_f32(float* g, const float* s, int64_t n, void* stream) {
+  TDVC_CHECK(g && s && n >= 0, "tdvc_sigmoid_backward_f32: bad arguments");
+  if (n) hipLaunchKernelGGL(sigmoid_backward_f32_kernel, grid1d(n), dim3(EW_BLOCK), 0, ST(stream), g, s, (long)n);
+  return tdvc_launch_status("tdvc_sigmoid_backward_f32");
+}
+extern "C" int tdvc_axpy_f32(float* dst, const float* src, float scale, int64_t n, void* stream) {
+  TDVC_CHECK(dst && src && n >= 0, "tdvc_axpy_f32: bad arguments");
+  if (n) hipLaunchKernelGGL(axpy_f32_kernel, grid1d(n), dim3(EW_BLOCK), 0, ST(stream), dst, src, scale, (long)n);
+  return tdvc_launch_status("tdvc_axpy_f32");
 }

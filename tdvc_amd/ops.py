@@ -444,7 +444,24 @@ def dcn_fused(x: FM, om: FM, pc: PackedConv, out: FM, groups=8, act=ACT_NONE, sl
     d.w, d.bias = pc.w.data_ptr(), pc.bias.data_ptr()
     d.groups, d.act, d.slope, d.round_before_act = groups, act, slope, int(round16)
     L.check(L.lib().tdvc_dcn_fused(C.byref(d), _stream()), "dcn_fused")
+    _rec("dcn_fused", x, om, pc, out, groups, act, slope)
     return out
+
+
+def sigmoid_f32(x: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(x)
+    L.check(L.lib().tdvc_sigmoid_f32(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "sigmoid_f32")
+    return out
+
+
+def sigmoid_backward_f32(g: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    L.check(L.lib().tdvc_sigmoid_backward_f32(g.data_ptr(), s.data_ptr(), g.numel(), _stream()), "sigmoid_backward_f32")
+    return g
+
+
+def axpy_f32(dst: torch.Tensor, src: torch.Tensor, scale: float) -> None:
+    assert dst.numel() == src.numel() and dst.dtype == src.dtype == torch.float32 and dst.is_contiguous() and src.is_contiguous()
+    L.check(L.lib().tdvc_axpy_f32(dst.data_ptr(), src.data_ptr(), scale, dst.numel(), _stream()), "axpy_f32")
 
 
 # ----------------------------------------------------------------------------- elementwise / SE

@@ -184,3 +184,33 @@ def test_offsetgen_backward(report):
         report(f"OffsetGen {name}: rel L2 err {e:.3e}")
         assert e < 3e-2, (name, e)
     _check_param_grads(dev, ref, report, 8e-2, "OffsetGen")
+
+
+def test_mcnet_backward(report):
+    """motion compensation: DCNv2 (offsets, masks, sampled features, weights) + refinement ResBlocks with two residuals"""
+    from oracle.tdvc_ref import blocks as ob
+    from tdvc_amd import autograd, ops
+    from tdvc_amd.model import modules as dm
+    dev, ref = _pair(dm.MCNet, ob.MCNet, 3)
+    B, H, W = 1, 32, 48
+    g = torch.Generator().manual_seed(31)
+    offset = rnd16(torch.randn(B, 64, H, W, generator=g) * 0.5).requires_grad_()
+    reff = rnd16(torch.randn(B, 64, H, W, generator=g) * 0.5).requires_grad_()
+    wgt = randn(B, 64, H, W, seed=32)
+    y = ref(offset, reff)
+    (y * wgt).sum().backward()
+    with autograd.record() as tape:
+        feats = ops.FM.zeros(B, H, W, 192)
+        ops.copy_cast(to_fm(reff.detach(), ops), feats.ch(64, 64))
+        off = to_fm(offset.detach(), ops)
+        out = ops.FM.empty(B, H, W, 64)
+        dev.run(off, feats, out)
+        ops.copy_cast(to_fm(wgt, ops), tape.grad(out))
+        tape.backward()
+        goff, gref = fm_to_cpu(tape.grad(off)), fm_to_cpu(tape.grad(feats.ch(64, 64)))
+    assert _rel(fm_to_cpu(out), y.detach()) < 5e-3
+    for name, got, want in (("doffset", goff, offset.grad), ("dref", gref, reff.grad)):
+        e = _rel(got, want)
+        report(f"MCNet {name}: rel L2 err {e:.3e}")
+        assert e < 4e-2, (name, e)
+    _check_param_grads(dev, ref, report, 5e-2, "MCNet")
