@@ -324,6 +324,11 @@ int tdvc_sigmoid_f32(const float* x, float* out, int64_t n, void* stream);
 int tdvc_sigmoid_backward_f32(float* g, const float* s, int64_t n, void* stream);
 int tdvc_axpy_f32(float* dst, const float* src, float scale, int64_t n, void* stream);
 
+/* backward of tdvc_match_gather (pnet.py:240-255): the matching indices carry no gradient; dfin += d(cat)/d(fin),
+ * dfref += the gathered blocks' gradients in gather form (fixed summation order, no atomics). */
+int tdvc_match_gather_backward(const tdvc_fmap* fin, const tdvc_fmap* fref, const int32_t* idx, int scale, int hp, int wp,
+                               const tdvc_fmap* dcat, const tdvc_fmap* dfin, const tdvc_fmap* dfref, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

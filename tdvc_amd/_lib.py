@@ -69,6 +69,7 @@ SIGNATURES = {
     "tdvc_sigmoid_f32": (_i, [_P, _P, _i64, _P]),
     "tdvc_sigmoid_backward_f32": (_i, [_P, _P, _i64, _P]),
     "tdvc_axpy_f32": (_i, [_P, _P, _f, _i64, _P]),
+    "tdvc_match_gather_backward": (_i, [_FM, _FM, _P, _i, _i, _i, _FM, _FM, _FM, _P]),
     "tdvc_conv_wgrad_work_floats": (_i64, [_i] * 6),
     "tdvc_conv_wgrad": (_i, [_FM, _FM] + [_i] * 6 + [_P] * 5 + [_f, _P, _P, _i64, _P]),
     "tdvc_dcn_fused": (_i, [C.POINTER(DcnDesc), _P]),

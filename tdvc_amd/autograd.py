@@ -134,8 +134,10 @@ def record_scale_act_res(tape: Tape, a: FM, out: FM, gate, act, slope, res, res_
             accumulate(g, tape.grad(out2))
         if res is not None and tape.needs_grad(res):
             accumulate(tape.grad(res), g, res_sign)
-        if act != ops.ACT_NONE:
-            raise NotImplementedError("autograd: scale_act_res with an activation")
+        if act in (ops.ACT_RELU, ops.ACT_LRELU):          # y = act(a * gate) + res: the sign of the argument is that of y - res
+            g = ops.act_backward(g, out, act, slope, res=res, out=FM.empty(g.N, g.H, g.W, g.C, dtype=g.t.dtype, device=g.t.device))
+        elif act != ops.ACT_NONE:
+            raise NotImplementedError(f"autograd: scale_act_res with activation {act}")
         if gate is not None:
             ops.gate_backward(g, a, gate, tape.grad(a) if tape.needs_grad(a) else None, tape.grad_tensor(gate))
         elif tape.needs_grad(a):
@@ -210,3 +212,7 @@ def record_dcn_fused(tape: Tape, x: FM, om: FM, pc, out: FM, groups, act, slope)
         ops.axpy_f32(param_grad(bias), gb, tape.inv_scale)
 
     tape.add(bwd)
+
+
+def record_match_gather(tape: Tape, fin: FM, fref: FM, idx, scale, cat: FM):
+    tape.add(lambda: ops.match_gather_backward(fin, fref, idx, scale, tape.grad(cat), tape.grad(fin), tape.grad(fref)))

@@ -423,6 +423,105 @@ __global__ void axpy_f32_kernel(float* dst, const float* src, float scale, long 
   if (i < n) dst[i] += scale * src[i];
 }
 
+// ---- backward of match_gather_kernel (FeatureFix, pnet.py:240-255): cat[p] = [a * cor, b * cor], a = fin[p],
+// b = fref[src(p)], cor = a.b / max(|a||b|, 1e-8).  Eight lanes per pixel (8 channels each), as in the forward.
+struct MatchGrad { float da[8], db[8]; };
+__device__ __forceinline__ MatchGrad match_pair_grad(const float a[8], const float b[8], const float ga[8], const float gb[8], int lanes) {
+  float w12 = 0.f, w1 = 0.f, w2 = 0.f, dc = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { w12 += a[j] * b[j]; w1 += a[j] * a[j]; w2 += b[j] * b[j]; dc += ga[j] * a[j] + gb[j] * b[j]; }
+  for (int o = 1; o < lanes; o <<= 1) {
+    w12 += __shfl_xor(w12, o);
+    w1 += __shfl_xor(w1, o);
+    w2 += __shfl_xor(w2, o);
+    dc += __shfl_xor(dc, o);
+  }
+  const float den = sqrtf(w1) * sqrtf(w2);
+  const bool live = den > 1e-8f;
+  const float D = live ? den : 1e-8f;
+  const float cor = w12 / D;
+  const float ka = live ? cor / w1 : 0.f, kb = live ? cor / w2 : 0.f;      // d(den)/da = den * a / |a|^2
+  MatchGrad r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    r.da[j] = ga[j] * cor + dc * (b[j] / D - ka * a[j]);
+    r.db[j] = gb[j] * cor + dc * (a[j] / D - kb * b[j]);
+  }
+  return r;
+}
+
+// dfin[p] += da(p)
+__global__ __launch_bounds__(256) void match_gather_backward_in_kernel(FMap fin, FMap fref, const int32_t* idx, int ks, int nbh, int nbw, FMap dcat, FMap dfin) {
+  const int lanes = fin.C / 8;
+  const long npix = (long)fin.H * fin.W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long t = i / lanes;
+  const int c = (int)(i % lanes) * 8;
+  const bool valid = t < npix * fin.N;
+  const long tc = valid ? t : 0;
+  const int n = (int)(tc / npix);
+  const long pix = tc % npix;
+  const int y = (int)(pix / fin.W), x = (int)(pix % fin.W);
+  const int m = idx[(long)n * nbh * nbw + (y / ks + 1) * nbw + (x / ks + 1)];
+  const int sy = (m / nbw - 1) * ks + y % ks, sx = (m % nbw - 1) * ks + x % ks;
+  float a[8], b[8], ga[8], gb[8];
+  load8(fin, n, pix, c, a);
+  if (sy >= 0 && sy < fref.H && sx >= 0 && sx < fref.W) {
+    load8(fref, n, (long)sy * fref.W + sx, c, b);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = 0.f;
+  }
+  load8(dcat, n, pix, c, ga);
+  load8(dcat, n, pix, fin.C + c, gb);
+  const MatchGrad r = match_pair_grad(a, b, ga, gb, lanes);
+  if (!valid) return;
+  float d[8];
+  load8(dfin, n, pix, c, d);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) d[j] += r.da[j];
+  store8(dfin, n, pix, c, d);
+}
+
+// dfref[q] += sum over the output blocks matched to q's block of db(p(q))   (gather form: no atomics, fixed order)
+__global__ __launch_bounds__(256) void match_gather_backward_ref_kernel(FMap fin, FMap fref, const int32_t* idx, int ks, int nbh, int nbw, FMap dcat, FMap dfref) {
+  const int lanes = fin.C / 8;
+  const long npix = (long)fref.H * fref.W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long t = i / lanes;
+  const int c = (int)(i % lanes) * 8;
+  const bool valid = t < npix * fref.N;
+  const long tc = valid ? t : 0;
+  const int n = (int)(tc / npix);
+  const long pix = tc % npix;
+  const int qy = (int)(pix / fref.W), qx = (int)(pix % fref.W);
+  const int mq = (qy / ks + 1) * nbw + (qx / ks + 1);
+  float b[8], acc[8];
+  load8(fref, n, pix, c, b);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  const int32_t* id = idx + (long)n * nbh * nbw;
+  for (int blk = 0; blk < nbh * nbw; ++blk) {
+    if (id[blk] != mq) continue;                           // uniform over the 8 lanes of a pixel
+    const int y = (blk / nbw - 1) * ks + qy % ks, x = (blk % nbw - 1) * ks + qx % ks;
+    if (y < 0 || y >= fin.H || x < 0 || x >= fin.W) continue;
+    const long p = (long)y * fin.W + x;
+    float a[8], ga[8], gb[8];
+    load8(fin, n, p, c, a);
+    load8(dcat, n, p, c, ga);
+    load8(dcat, n, p, fin.C + c, gb);
+    const MatchGrad r = match_pair_grad(a, b, ga, gb, lanes);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += r.db[j];
+  }
+  if (!valid) return;
+  float d[8];
+  load8(dfref, n, pix, c, d);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) d[j] += acc[j];
+  store8(dfref, n, pix, c, d);
+}
+
 }  // namespace
 
 extern "C" int tdvc_act_backward(const tdvc_fmap* g, const tdvc_fmap* y, const tdvc_fmap* res, int act, float slope, const tdvc_fmap* out, void* stream) {
@@ -553,4 +652,19 @@ extern "C" int tdvc_axpy_f32(float* dst, const float* src, float scale, int64_t 
   TDVC_CHECK(dst && src && n >= 0, "tdvc_axpy_f32: bad arguments");
   if (n) hipLaunchKernelGGL(axpy_f32_kernel, grid1d(n), dim3(EW_BLOCK), 0, ST(stream), dst, src, scale, (long)n);
   return tdvc_launch_status("tdvc_axpy_f32");
+}
+
+extern "C" int tdvc_match_gather_backward(const tdvc_fmap* fin, const tdvc_fmap* fref, const int32_t* idx, int scale, int hp, int wp,
+                                          const tdvc_fmap* dcat, const tdvc_fmap* dfin, const tdvc_fmap* dfref, void* stream) {
+  TDVC_CHECK(fin && fref && idx && dcat && dfin && dfref && fmap_ok16(*fin) && fmap_ok16(*fref) && fmap_ok16(*dcat) && fmap_ok16(*dfin) && fmap_ok16(*dfref),
+             "tdvc_match_gather_backward: bad fmaps");
+  TDVC_CHECK(fin->C == 64 && fref->C == 64 && dcat->C == 128 && dfin->C == 64 && dfref->C == 64 && same_geom(*fin, *fref) && same_geom(*fin, *dcat) &&
+                 same_geom(*fin, *dfin) && same_geom(*fin, *dfref), "tdvc_match_gather_backward: needs C=64 / dcat C=128");
+  const int ks = 3 * scale;
+  const int nbh = (fin->H + ks) / ks + 1, nbw = (fin->W + ks) / ks + 1;
+  TDVC_CHECK(nbh == (hp + 3) / 3 + 1 && nbw == (wp + 3) / 3 + 1, "tdvc_match_gather_backward: fold grid != patch grid");
+  const long total = (long)fin->N * fin->H * fin->W * 8;
+  hipLaunchKernelGGL(match_gather_backward_in_kernel, grid1d(total), dim3(256), 0, ST(stream), to_dev(*fin), to_dev(*fref), idx, ks, nbh, nbw, to_dev(*dcat), to_dev(*dfin));
+  hipLaunchKernelGGL(match_gather_backward_ref_kernel, grid1d(total), dim3(256), 0, ST(stream), to_dev(*fin), to_dev(*fref), idx, ks, nbh, nbw, to_dev(*dcat), to_dev(*dfref));
+  return tdvc_launch_status("tdvc_match_gather_backward");
 }

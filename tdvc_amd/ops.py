@@ -587,6 +587,13 @@ def match_gather(fin: FM, fref: FM, idx: torch.Tensor, scale: int, cat: FM):
     df, dr, dc = fin.desc(), fref.desc(), cat.desc()
     L.check(L.lib().tdvc_match_gather(C.byref(df), C.byref(dr), idx.data_ptr(), scale, fin.H // scale, fin.W // scale,
                                       C.byref(dc), _stream()), "match_gather")
+    _rec("match_gather", fin, fref, idx, scale, cat)
+
+
+def match_gather_backward(fin: FM, fref: FM, idx: torch.Tensor, scale: int, dcat: FM, dfin: FM, dfref: FM) -> None:
+    d1, d2, d3, d4, d5 = fin.desc(), fref.desc(), dcat.desc(), dfin.desc(), dfref.desc()
+    L.check(L.lib().tdvc_match_gather_backward(C.byref(d1), C.byref(d2), idx.data_ptr(), scale, fin.H // scale, fin.W // scale,
+                                               C.byref(d3), C.byref(d4), C.byref(d5), _stream()), "match_gather_backward")
 
 
 # ----------------------------------------------------------------------------- entropy model

@@ -214,3 +214,44 @@ def test_mcnet_backward(report):
         report(f"MCNet {name}: rel L2 err {e:.3e}")
         assert e < 4e-2, (name, e)
     _check_param_grads(dev, ref, report, 5e-2, "MCNet")
+
+
+def test_featurefix_backward(report):
+    """in-loop filter in training mode (scale-8 matching): two extractors, matched-block gather with cosine weights
+    (gradient to both feature maps), fusion convs, SE with LeakyReLU, clamp, planar fp32 output"""
+    from oracle.tdvc_ref import blocks as ob
+    from tdvc_amd import autograd, ops
+    from tdvc_amd.model import modules as dm
+    dev, ref = _pair(dm.FeatureFix, ob.FeatureFix)
+    dev.train()
+    ref.train()
+    B, H, W = 1, 96, 96
+    g = torch.Generator().manual_seed(41)
+    x = rnd16(torch.randn(B, 64, H, W, generator=g) * 0.5).requires_grad_()
+    base = torch.nn.functional.avg_pool2d(torch.rand(B, 3, H + 4, W + 4, generator=g), 5, 1, 2)
+    iframe = rnd16(base[..., 2:-2, 2:-2].contiguous())
+    refs = iframe.unsqueeze(1).repeat(1, 4, 1, 1, 1)
+    wgt = randn(B, 3, H, W, seed=42)
+    y = ref(x, refs).clamp(0.0, 1.0)
+    (y * wgt).sum().backward()
+    with autograd.record() as tape:
+        xf = to_fm(x.detach(), ops)
+        i8 = to_fm(iframe, ops, Cpad=8)
+        tape.mark_input(i8)
+        trace = {}
+        rgb = dev.run(xf, i8, training=True, trace=trace)
+        tape.grad_tensor(rgb).copy_(wgt.cuda())
+        tape.backward()
+        gx = fm_to_cpu(tape.grad(xf))
+    # the matching must agree for the gradients to be comparable
+    with torch.no_grad():
+        fin, fref = ref.FeatureExtract_input(x), ref.FeatureExtract_ref(iframe)
+        ind, _ = ref.match(fin, fref, 8)
+    same = float((trace["ff_idx"].cpu().long() == ind).float().mean())
+    report(f"FeatureFix: matching indices equal to the oracle's for {same:.3f} of the patches")
+    assert same == 1.0
+    assert _rel(rgb.cpu(), y.detach()) < 5e-3
+    e = _rel(gx, x.grad)
+    report(f"FeatureFix dx: rel L2 err {e:.3e}")
+    assert e < 4e-2
+    _check_param_grads(dev, ref, report, 6e-2, "FeatureFix")
