@@ -275,12 +275,13 @@ int tdvc_pack_conv_weights_indexed(const float* w, const int32_t* row_off, const
 /* dW[row_off[co] + chan_off[ci] + tap_off[t]] += scale * sum_{n,oy,ox} g[n,oy,ox,co] * x[n, oy*stride + dy_t - pad, ox*stride + dx_t - pad, ci]
  * for the forward conv y = conv(x, W); g = dL/dy (fp16 fmap, >= cout channels; for a sub-pixel conv the un-shuffled
  * gradient in packed-row order), dW the fp32 parameter gradient.  row_off[cout] / chan_off[x.C] / tap_off[ntaps] are the
- * layer's forward packing tables (device int32; negative row / channel entries are skipped).  Two order-fixed stages
+ * layer's forward packing tables (device int32; negative row / channel entries are skipped); square_x contracts with
+ * x^2 instead of x (GDN norm pool).  Two order-fixed stages
  * through `work` (>= tdvc_conv_wgrad_work_floats(cout, x.C, ntaps, N, Ho, Wo) floats of device memory). */
 int64_t tdvc_conv_wgrad_work_floats(int cout, int cin, int ntaps, int N, int Ho, int Wo);
 int tdvc_conv_wgrad(const tdvc_fmap* g, const tdvc_fmap* x, int cout, int kh, int kw, int stride, int pad,
                     int ntaps, const int8_t* tap_dy, const int8_t* tap_dx, const int32_t* row_off, const int32_t* chan_off,
-                    const int32_t* tap_off, float scale, float* dw, float* work, int64_t work_floats, void* stream);
+                    const int32_t* tap_off, int square_x, float scale, float* dw, float* work, int64_t work_floats, void* stream);
 
 /* out = g * act'(z), ReLU / LeakyReLU, the sign of z taken from the stored output (y - res); out may alias g. */
 int tdvc_act_backward(const tdvc_fmap* g, const tdvc_fmap* y, const tdvc_fmap* res, int act, float slope, const tdvc_fmap* out, void* stream);
@@ -328,6 +329,12 @@ int tdvc_axpy_f32(float* dst, const float* src, float scale, int64_t n, void* st
  * dfref += the gathered blocks' gradients in gather form (fixed summation order, no atomics). */
 int tdvc_match_gather_backward(const tdvc_fmap* fin, const tdvc_fmap* fref, const int32_t* idx, int scale, int hp, int wp,
                                const tdvc_fmap* dcat, const tdvc_fmap* dfin, const tdvc_fmap* dfref, void* stream);
+
+/* GDN / inverse GDN backward, elementwise part (y = x * n^(-1/2) | x * n^(+1/2), n = beta + gamma . x^2 recomputed in
+ * fp32): dx += g * n^(-+1/2);  dn = g * x * (-+1/2) * n^(-+1/2 - 1) (fp16, feeds conv_dgrad / conv_wgrad of the norm pool). */
+int tdvc_gdn_backward(const tdvc_fmap* g, const tdvc_fmap* x, const tdvc_fmap* n32, int inverse, const tdvc_fmap* dn, const tdvc_fmap* dx, void* stream);
+/* dx += 2 * x * t (chain rule through x^2). */
+int tdvc_mul2_accumulate(const tdvc_fmap* dx, const tdvc_fmap* x, const tdvc_fmap* t, void* stream);
 
 #ifdef __cplusplus
 }

@@ -71,7 +71,9 @@ SIGNATURES = {
     "tdvc_axpy_f32": (_i, [_P, _P, _f, _i64, _P]),
     "tdvc_match_gather_backward": (_i, [_FM, _FM, _P, _i, _i, _i, _FM, _FM, _FM, _P]),
     "tdvc_conv_wgrad_work_floats": (_i64, [_i] * 6),
-    "tdvc_conv_wgrad": (_i, [_FM, _FM] + [_i] * 6 + [_P] * 5 + [_f, _P, _P, _i64, _P]),
+    "tdvc_conv_wgrad": (_i, [_FM, _FM] + [_i] * 6 + [_P] * 5 + [_i, _f, _P, _P, _i64, _P]),
+    "tdvc_gdn_backward": (_i, [_FM, _FM, _FM, _i, _FM, _FM, _P]),
+    "tdvc_mul2_accumulate": (_i, [_FM, _FM, _FM, _P]),
     "tdvc_dcn_fused": (_i, [C.POINTER(DcnDesc), _P]),
     "tdvc_dcn_v2_forward_f32": (_i, [_P] * 6 + [_i] * 14 + [_P]),
     "tdvc_dcn_v2_backward_f32": (_i, [_P] * 12 + [_i] * 14 + [_P]),

@@ -94,8 +94,9 @@ def accumulate(dst: FM, src: FM, sign: float = 1.0):
 
 # ---------------------------------------------------------------------- op records (called from ops.* when taping)
 def record_conv(tape: Tape, x: FM, pc, y, act, slope, res, res2, gdn, aux, square, nchw_out):
-    if gdn != ops.GDN_NONE or square:
-        raise NotImplementedError("autograd: GDN convs are recorded by the coder (record_gdn)")
+    if gdn != ops.GDN_NONE:
+        return record_gdn(tape, x, pc, y, res, gdn)
+    assert not square
     assert not (act not in (ops.ACT_NONE,) and res2 is not None), "autograd: activation + two residuals is not on the path"
     weight, bias = pc.param_w, pc.param_b
 
@@ -216,3 +217,26 @@ def record_dcn_fused(tape: Tape, x: FM, om: FM, pc, out: FM, groups, act, slope)
 
 def record_match_gather(tape: Tape, fin: FM, fref: FM, idx, scale, cat: FM):
     tape.add(lambda: ops.match_gather_backward(fin, fref, idx, scale, tape.grad(cat), tape.grad(fin), tape.grad(fref)))
+
+
+def record_gdn(tape: Tape, x: FM, pc, y: FM, res, gdn):
+    """y = x * n^(-1/2) (GDN) | x * n^(+1/2) (inverse GDN) [+ res], n = beta + gamma . x^2 (a 1x1 conv on x^2).
+    The fused forward keeps no `n`: it is recomputed in fp32 by the same conv kernel."""
+    owner = pc.owner                              # the GDN module: maps (dgamma_eff, dbeta_eff) to its raw parameters
+
+    def bwd():
+        g = tape.grad(y)
+        if res is not None and tape.needs_grad(res):
+            accumulate(tape.grad(res), g)
+        n32 = ops.conv(x, pc, square=True, out_dtype=torch.float32)
+        dx = tape.grad(x)
+        dn = ops.gdn_backward(g, x, n32, gdn == ops.GDN_INV, dx)
+        t = ops.conv_dgrad(pc, dn, FM.empty(x.N, x.H, x.W, x.C, device=x.t.device), accumulate=False)
+        ops.mul2_accumulate(dx, x, t)
+        dgamma = torch.zeros_like(pc.wsrc)
+        dbeta = torch.zeros_like(pc.bsrc)
+        ops.conv_wgrad(pc, dn, x, dgamma.view(-1), scale=tape.inv_scale, square_x=True)
+        ops.conv_bgrad(pc, dn, dbeta, scale=tape.inv_scale)
+        owner.accumulate_param_grads(dgamma.view(dgamma.shape[0], dgamma.shape[1]), dbeta)
+
+    tape.add(bwd)

@@ -522,6 +522,54 @@ __global__ __launch_bounds__(256) void match_gather_backward_ref_kernel(FMap fin
   store8(dfref, n, pix, c, d);
 }
 
+__global__ void gdn_backward_kernel(FMap g, FMap x, FMap n32, int inverse, FMap dn, FMap dx) {
+  const long npix = (long)g.H * g.W;
+  const int chunks = g.C / 8;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * g.N * chunks) return;
+  const int c = (int)(i % chunks) * 8;
+  const long q = i / chunks;
+  const int n = (int)(q / npix);
+  const long pix = q % npix;
+  float gv[8], xv[8], nv[8], dv[8], dnv[8];
+  load8(g, n, pix, c, gv);
+  load8(x, n, pix, c, xv);
+  load8(n32, n, pix, c, nv);
+  load8(dx, n, pix, c, dv);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (inverse) {
+      const float r = sqrtf(nv[j]);
+      dv[j] += gv[j] * r;
+      dnv[j] = 0.5f * gv[j] * xv[j] / r;
+    } else {
+      const float r = rsqrtf(nv[j]);
+      dv[j] += gv[j] * r;
+      dnv[j] = -0.5f * gv[j] * xv[j] * r / nv[j];
+    }
+  }
+  store8(dx, n, pix, c, dv);
+  store8(dn, n, pix, c, dnv);
+}
+
+__global__ void mul2_accumulate_kernel(FMap dx, FMap x, FMap t) {
+  const long npix = (long)dx.H * dx.W;
+  const int chunks = dx.C / 8;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * dx.N * chunks) return;
+  const int c = (int)(i % chunks) * 8;
+  const long q = i / chunks;
+  const int n = (int)(q / npix);
+  const long pix = q % npix;
+  float dv[8], xv[8], tv[8];
+  load8(dx, n, pix, c, dv);
+  load8(x, n, pix, c, xv);
+  load8(t, n, pix, c, tv);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dv[j] += 2.f * xv[j] * tv[j];
+  store8(dx, n, pix, c, dv);
+}
+
 }  // namespace
 
 extern "C" int tdvc_act_backward(const tdvc_fmap* g, const tdvc_fmap* y, const tdvc_fmap* res, int act, float slope, const tdvc_fmap* out, void* stream) {
@@ -667,4 +715,21 @@ extern "C" int tdvc_match_gather_backward(const tdvc_fmap* fin, const tdvc_fmap*
   hipLaunchKernelGGL(match_gather_backward_in_kernel, grid1d(total), dim3(256), 0, ST(stream), to_dev(*fin), to_dev(*fref), idx, ks, nbh, nbw, to_dev(*dcat), to_dev(*dfin));
   hipLaunchKernelGGL(match_gather_backward_ref_kernel, grid1d(total), dim3(256), 0, ST(stream), to_dev(*fin), to_dev(*fref), idx, ks, nbh, nbw, to_dev(*dcat), to_dev(*dfref));
   return tdvc_launch_status("tdvc_match_gather_backward");
+}
+
+extern "C" int tdvc_gdn_backward(const tdvc_fmap* g, const tdvc_fmap* x, const tdvc_fmap* n32, int inverse, const tdvc_fmap* dn, const tdvc_fmap* dx, void* stream) {
+  TDVC_CHECK(g && x && n32 && dn && dx && fmap_any(*g) && fmap_ok16(*x) && fmap_ok32(*n32) && fmap_ok16(*dn) && fmap_ok16(*dx) && same_geom(*g, *x) &&
+                 same_geom(*g, *n32) && same_geom(*g, *dn) && same_geom(*g, *dx) && (g->C % 8) == 0 && x->C >= g->C && n32->C >= g->C && dn->C >= g->C &&
+                 dx->C >= g->C, "tdvc_gdn_backward: bad arguments");
+  const long total = (long)g->N * g->H * g->W * (g->C / 8);
+  hipLaunchKernelGGL(gdn_backward_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*g), to_dev(*x), to_dev(*n32), inverse, to_dev(*dn), to_dev(*dx));
+  return tdvc_launch_status("tdvc_gdn_backward");
+}
+
+extern "C" int tdvc_mul2_accumulate(const tdvc_fmap* dx, const tdvc_fmap* x, const tdvc_fmap* t, void* stream) {
+  TDVC_CHECK(dx && x && t && fmap_ok16(*dx) && fmap_ok16(*x) && fmap_ok16(*t) && same_geom(*dx, *x) && same_geom(*dx, *t) && x->C >= dx->C && t->C >= dx->C,
+             "tdvc_mul2_accumulate: bad arguments");
+  const long total = (long)dx->N * dx->H * dx->W * (dx->C / 8);
+  hipLaunchKernelGGL(mul2_accumulate_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*dx), to_dev(*x), to_dev(*t));
+  return tdvc_launch_status("tdvc_mul2_accumulate");
 }

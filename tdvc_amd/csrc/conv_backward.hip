@@ -68,6 +68,7 @@ struct WgradParams {
   int co_tiles, ci_tiles;
   int blocks_x, blocks_y, nblocks;              // pixel blocks per image, total over the batch
   int tih, tiw;                                 // X tile extent in pixels
+  int square_x;                                 // contract with x^2 (GDN norm pool: dgamma = sum dnorm * x^2)
   float* work;                                  // [P][co_tiles*64][ci_tiles*32][ntaps_all]
 };
 
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
       if (iy >= 0 && iy < p.x.H && ix >= 0 && ix < p.x.W && c < p.x.C)
         v = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(p.x.p) + (long)n * p.x.sn + ((long)iy * p.x.W + ix) * p.x.sp + c);
+      if (p.square_x) v = v * v;
       *reinterpret_cast<half8*>(xt + px * PSX + c8 * 16) = v;
     }
     __syncthreads();
@@ -234,7 +236,7 @@ extern "C" int64_t tdvc_conv_wgrad_work_floats(int cout, int cin, int ntaps, int
 
 extern "C" int tdvc_conv_wgrad(const tdvc_fmap* g, const tdvc_fmap* x, int cout, int kh, int kw, int stride, int pad,
                                int ntaps, const int8_t* tap_dy, const int8_t* tap_dx, const int32_t* row_off, const int32_t* chan_off,
-                               const int32_t* tap_off, float scale, float* dw, float* work, int64_t work_floats, void* stream) {
+                               const int32_t* tap_off, int square_x, float scale, float* dw, float* work, int64_t work_floats, void* stream) {
   TDVC_CHECK(g && x && dw && work && tap_dy && tap_dx && row_off && chan_off && tap_off, "tdvc_conv_wgrad: null pointer");
   TDVC_CHECK(fmap_ok16(*g) && fmap_ok16(*x) && g->N == x->N, "tdvc_conv_wgrad: fmaps must be fp16 with matching batch");
   TDVC_CHECK(stride == 1 || stride == 2, "tdvc_conv_wgrad: stride %d", stride);
@@ -259,6 +261,7 @@ extern "C" int tdvc_conv_wgrad(const tdvc_fmap* g, const tdvc_fmap* x, int cout,
   const size_t lds = (size_t)WG_TH * WG_TW * PSG + (size_t)p.tih * p.tiw * PSX;
   TDVC_CHECK(lds <= 160 * 1024, "tdvc_conv_wgrad: LDS plan %zu bytes too large", lds);
   p.work = work;
+  p.square_x = square_x;
   const int groups = (ntaps + WG_MAXT - 1) / WG_MAXT;
   const int workers = wgrad_workers(p.co_tiles, p.ci_tiles, groups, p.nblocks);
   static bool attr_done = false;

@@ -56,9 +56,27 @@ class GDN(nn.Module, PackCache):
             g = self.gamma_reparam.effective(self.gamma.detach())
             b = self.beta_reparam.effective(self.beta.detach())
             c = g.shape[0]
-            return ops.pack_conv(g.reshape(c, c, 1, 1), b, stride=1, pad=0, device=self.gamma.device)
+            pc = ops.pack_conv(g.reshape(c, c, 1, 1).contiguous(), b.contiguous(), stride=1, pad=0, device=self.gamma.device)
+            pc.owner = self
+            return pc
         pc = self._pk("gdn", build)
         return ops.conv(x, pc, out=out, square=True, gdn=GDN_INV if self.inverse else GDN_FWD, aux=x, res=res)
+
+    def refresh_packed(self):
+        """after an optimizer step: effective gamma / beta recomputed into the packed layer's source tensors, re-packed"""
+        pc = self.__dict__.get("_packed", {}).get("gdn")
+        if pc is not None:
+            with torch.no_grad():
+                pc.wsrc.copy_(self.gamma_reparam.effective(self.gamma).reshape(pc.wsrc.shape))
+                pc.bsrc.copy_(self.beta_reparam.effective(self.beta))
+            pc.repack()
+
+    def accumulate_param_grads(self, dgamma_eff: torch.Tensor, dbeta_eff: torch.Tensor):
+        """chain rule through the non-negative reparametrisation (parameter space, 128 x 128 values: plain autograd)"""
+        with torch.enable_grad():
+            g = self.gamma_reparam.effective(self.gamma)
+            b = self.beta_reparam.effective(self.beta)
+            torch.autograd.backward([g, b], [dgamma_eff.to(g.dtype), dbeta_eff.to(b.dtype)])
 
 
 def conv3x3(cin, cout, stride=1):

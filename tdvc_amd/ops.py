@@ -141,6 +141,7 @@ class PackedConv:
     dgrad: "PackedConv | None" = None      # lazily built data-gradient conv (ops.conv_dgrad)
     param_w: torch.Tensor | None = None    # the nn.Parameters that own wsrc / bsrc (gradient accumulators live on them)
     param_b: torch.Tensor | None = None
+    owner: object | None = None            # module that maps this layer's weight gradient to its own parameters (GDN)
 
     def repack(self):
         """re-pack from the (updated) fp32 parameters: one kernel launch, plus the bias gather"""
@@ -349,7 +350,7 @@ def conv_dgrad(pc: PackedConv, g: FM, dx: FM, accumulate=True) -> FM:
     return conv(g, dpc, out=dx, res=dx if accumulate else None)
 
 
-def conv_wgrad(pc: PackedConv, g: FM, x: FM, dw: torch.Tensor, scale=1.0) -> None:
+def conv_wgrad(pc: PackedConv, g: FM, x: FM, dw: torch.Tensor, scale=1.0, square_x=False) -> None:
     """dW += scale * dL/dW (fp32, the parameter's own layout); `g` as in conv_dgrad"""
     o = pc.orig
     tb = pc.__dict__.get("_wg_tables")
@@ -366,7 +367,7 @@ def conv_wgrad(pc: PackedConv, g: FM, x: FM, dw: torch.Tensor, scale=1.0) -> Non
     dxs = (C.c_int8 * len(o["taps"]))(*[t[1] for t in o["taps"]])
     dg, dxd = g.desc(), x.desc()
     L.check(lib.tdvc_conv_wgrad(C.byref(dg), C.byref(dxd), pc.cout, o["kh"], o["kw"], o["stride"], o["pad"], len(o["taps"]), dy, dxs,
-                                tb.row_off.data_ptr(), tb.chan_off.data_ptr(), tb.tap_off.data_ptr(), scale, dw.data_ptr(),
+                                tb.row_off.data_ptr(), tb.chan_off.data_ptr(), tb.tap_off.data_ptr(), int(square_x), scale, dw.data_ptr(),
                                 work.data_ptr(), nwork, _stream()), "conv_wgrad")
 
 
@@ -382,6 +383,19 @@ def conv_bgrad(pc: PackedConv, g: FM, db: torch.Tensor, scale=1.0) -> None:
     dg = g.desc()
     L.check(lib.tdvc_bias_grad(C.byref(dg), pc.cout, idx.data_ptr() if idx is not None else None, scale, db.data_ptr(), work.data_ptr(), nwork,
                                _stream()), "bias_grad")
+
+
+def gdn_backward(g: FM, x: FM, n32: FM, inverse: bool, dx: FM) -> FM:
+    """-> dn (fp16); dx += g * n^(-+1/2)"""
+    dn = FM.empty(g.N, g.H, g.W, g.C, device=g.t.device)
+    d1, d2, d3, d4, d5 = g.desc(), x.desc(), n32.desc(), dn.desc(), dx.desc()
+    L.check(L.lib().tdvc_gdn_backward(C.byref(d1), C.byref(d2), C.byref(d3), int(inverse), C.byref(d4), C.byref(d5), _stream()), "gdn_backward")
+    return dn
+
+
+def mul2_accumulate(dx: FM, x: FM, t: FM) -> None:
+    d1, d2, d3 = dx.desc(), x.desc(), t.desc()
+    L.check(L.lib().tdvc_mul2_accumulate(C.byref(d1), C.byref(d2), C.byref(d3), _stream()), "mul2_accumulate")
 
 
 def copy_cast(src: FM, dst: FM) -> FM:

@@ -255,3 +255,70 @@ def test_featurefix_backward(report):
     report(f"FeatureFix dx: rel L2 err {e:.3e}")
     assert e < 4e-2
     _check_param_grads(dev, ref, report, 6e-2, "FeatureFix")
+
+
+def test_coder_blocks_backward(report):
+    """analysis / synthesis blocks of the coders: stride-2 conv (space-to-depth forward, sub-pixel data gradient),
+    1x1 stride-2 skip, GDN / inverse GDN (norm pool recomputed, chain through the reparametrisation), sub-pixel convs"""
+    import torch.nn as nn
+    from oracle.tdvc_ref import coder as oc
+    from tdvc_amd import autograd, ops, synth
+    from tdvc_amd.model import coder as dc
+
+    class RefNet(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.down = oc.ResidualBlockWithStride(64, 128, 2)
+            self.rb = oc.ResidualBlock(128, 128)
+            self.up = oc.ResidualBlockUpsample(128, 128, 2)
+
+        def forward(self, x):
+            return self.up(self.rb(self.down(x)))
+
+    class DevNet(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.down = dc.ResidualBlockWithStride(64, 128, 2)
+            self.rb = dc.ResidualBlock(128, 128)
+            self.up = dc.ResidualBlockUpsample(128, 128, 2)
+
+        def run(self, x):
+            return self.up.run(self.rb.run(self.down.run(x)))
+
+    ref = RefNet()
+    synth.fill_parameters(ref)
+    dev = DevNet()
+    dev.load_state_dict(ref.state_dict())
+    dev = dev.cuda()
+    x = rnd16(randn(2, 64, 32, 48, seed=51) * 0.5).requires_grad_()
+    wgt = randn(2, 128, 32, 48, seed=52)
+    y = ref(x)
+    (y * wgt).sum().backward()
+    with autograd.record() as tape:
+        xf = to_fm(x.detach(), ops)
+        out = dev.run(xf)
+        ops.copy_cast(to_fm(wgt, ops), tape.grad(out))
+        tape.backward()
+        gx = fm_to_cpu(tape.grad(xf))
+    assert _rel(fm_to_cpu(out), y.detach()) < 5e-3
+    e = _rel(gx, x.grad)
+    report(f"coder blocks dx: rel L2 err {e:.3e}")
+    assert e < 3e-2
+    _check_param_grads(dev, ref, report, 5e-2, "coder blocks")
+    # an optimizer-style in-place update + refresh changes the packed GDN layers
+    with torch.no_grad():
+        for p in dev.parameters():
+            p.add_(0.01 * p.grad / (p.grad.abs().max() + 1e-12))
+    for m in dev.modules():
+        if isinstance(m, dc.GDN):
+            m.refresh_packed()
+        for pc in m.__dict__.get("_packed", {}).values():
+            if hasattr(pc, "repack") and not isinstance(m, dc.GDN):
+                pc.repack()
+    ref.load_state_dict(dev.state_dict())
+    with torch.no_grad():
+        y2 = ref(x.detach())
+    out2 = dev.run(to_fm(x.detach(), ops))
+    e2 = _rel(fm_to_cpu(out2), y2)
+    report(f"coder blocks forward after update + repack: rel L2 err {e2:.3e}")
+    assert e2 < 5e-3
