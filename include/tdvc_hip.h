@@ -336,6 +336,12 @@ int tdvc_gdn_backward(const tdvc_fmap* g, const tdvc_fmap* x, const tdvc_fmap* n
 /* dx += 2 * x * t (chain rule through x^2). */
 int tdvc_mul2_accumulate(const tdvc_fmap* dx, const tdvc_fmap* x, const tdvc_fmap* t, void* stream);
 
+/* backward of the rate terms in training mode (additive uniform noise), bits = -log2(likelihood):
+ * tdvc_eb_backward: dz += gscale * dbits/dz, dparams[C][59] += gscale * dbits/d(packed parameters);
+ * tdvc_gc_backward: dy += gscale * dbits/dy, dgp[.., 0:M] (scales) and dgp[.., M:2M] (means) likewise. */
+int tdvc_eb_backward(const tdvc_fmap* z, const float* params, const tdvc_fmap* noise, float gscale, const tdvc_fmap* dz, float* dparams, void* stream);
+int tdvc_gc_backward(const tdvc_fmap* y, const tdvc_fmap* gp, const tdvc_fmap* noise, float gscale, const tdvc_fmap* dy, const tdvc_fmap* dgp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -237,12 +237,14 @@ class EntropyBottleneck(nn.Module):
         sign = -torch.sign(lower + upper).detach()
         return torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
 
-    def forward(self, x):
+    def forward(self, x, noise=None):
+        """`noise` (same shape as x, U(-1/2, 1/2)): test hook that replaces the training-mode draw"""
         xp = x.permute(1, 0, 2, 3).contiguous()
         shape = xp.shape
         v = xp.reshape(shape[0], 1, -1)
         if self.training:
-            out = v + torch.empty_like(v).uniform_(-0.5, 0.5)
+            nz = torch.empty_like(v).uniform_(-0.5, 0.5) if noise is None else noise.permute(1, 0, 2, 3).reshape(shape[0], 1, -1)
+            out = v + nz
         else:
             med = self.medians()
             out = torch.round(v - med) + med
@@ -316,9 +318,9 @@ class GaussianConditional(nn.Module):
         v = torch.abs(values)
         return self.std_cdf((0.5 - v) / scales) - self.std_cdf((-0.5 - v) / scales)
 
-    def forward(self, y, scales, means, training):
+    def forward(self, y, scales, means, training, noise=None):
         if training:
-            out = y + torch.empty_like(y).uniform_(-0.5, 0.5)
+            out = y + (torch.empty_like(y).uniform_(-0.5, 0.5) if noise is None else noise)
         else:
             out = torch.round(y - means) + means
         lik = self.likelihood_lower_bound(self.likelihood(out - means, scales))
@@ -498,19 +500,21 @@ class Cheng2020Anchor(nn.Module):
         self.gaussian_conditional = GaussianConditional()
 
     # -- forward (`pnet.py:34,58`) -----------------------------------------------------
-    def forward(self, x):
+    def forward(self, x, noise=None):
+        """`noise`: optional dict of U(-1/2, 1/2) tensors {"z", "y", "y_lik"} replacing the three training-mode draws"""
+        noise = noise or {}
         y = self.g_a(x)
         z = self.h_a(y)
-        z_hat, z_lik = self.entropy_bottleneck(z)
+        z_hat, z_lik = self.entropy_bottleneck(z, noise.get("z"))
         params = self.h_s(z_hat)
         if self.training:
-            y_hat = y + torch.empty_like(y).uniform_(-0.5, 0.5)
+            y_hat = y + (torch.empty_like(y).uniform_(-0.5, 0.5) if noise.get("y") is None else noise["y"])
         else:
             y_hat = torch.round(y)
         ctx = self.context_prediction(y_hat)
         gp = self.entropy_parameters(torch.cat((params, ctx), 1))
         scales, means = gp.chunk(2, 1)
-        _, y_lik = self.gaussian_conditional(y, scales, means, self.training)
+        _, y_lik = self.gaussian_conditional(y, scales, means, self.training, noise.get("y_lik"))
         return {"x_hat": self.g_s(y_hat), "likelihoods": {"y": y_lik, "z": z_lik},
                 "_debug": {"y": y, "z": z, "z_hat": z_hat, "y_hat": y_hat, "scales": scales, "means": means}}
 

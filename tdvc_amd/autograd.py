@@ -28,6 +28,7 @@ class Tape:
         self.keep: list = []                      # activation tensors referenced by the closures stay alive
         self.nograd: set[int] = set()             # base buffers that need no gradient (network inputs)
         self.loss_scale = float(loss_scale)
+        self.rate_grad = 0.0                      # dLoss/d(bits) of every rate term, set before backward() (1 / pixels for bpp)
 
     # ------------------------------------------------------------------ gradient views
     def _base(self, t: torch.Tensor) -> torch.Tensor:
@@ -240,3 +241,30 @@ def record_gdn(tape: Tape, x: FM, pc, y: FM, res, gdn):
         owner.accumulate_param_grads(dgamma.view(dgamma.shape[0], dgamma.shape[1]), dbeta)
 
     tape.add(bwd)
+
+
+def record_eb_forward(tape: Tape, z: FM, params: torch.Tensor, z_hat: FM, noise):
+    if noise is None:
+        raise NotImplementedError("autograd: the factorised prior is differentiable in training mode (additive noise) only")
+    owner = params.owner                          # the EntropyBottleneck module
+
+    def bwd():
+        dz = tape.grad(z)
+        accumulate(dz, tape.grad(z_hat))          # z_hat = z + noise
+        dp = torch.zeros_like(params)
+        ops.eb_backward(z, params, noise, tape.rate_grad * tape.loss_scale, dz, dp)
+        owner.accumulate_param_grads(dp * tape.inv_scale)
+
+    tape.add(bwd)
+
+
+def record_gc_forward(tape: Tape, y: FM, gp: FM, noise):
+    if noise is None:
+        raise NotImplementedError("autograd: the Gaussian conditional is differentiable in training mode (additive noise) only")
+    tape.add(lambda: ops.gc_backward(y, gp, noise, tape.rate_grad * tape.loss_scale, tape.grad(y), tape.grad(gp)))
+
+
+def record_quantize(tape: Tape, y: FM, out: FM, noise):
+    if noise is None:
+        raise NotImplementedError("autograd: rounding has no gradient; training uses additive noise")
+    tape.add(lambda: accumulate(tape.grad(y), tape.grad(out)))

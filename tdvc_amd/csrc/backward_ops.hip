@@ -570,6 +570,145 @@ __global__ void mul2_accumulate_kernel(FMap dx, FMap x, FMap t) {
   store8(dx, n, pix, c, dv);
 }
 
+// ---------------------------------------------------------------- entropy-model rate terms (training: additive noise)
+constexpr int EBP = EB_NP;  // floats per channel of the packed factorised-prior parameters (pointwise_common.h::eb_logits)
+
+// logits_cumulative(v) and its adjoint: gp[] += gout * d logits / d params, returns gout * d logits / d v
+__device__ __forceinline__ float eb_logits_backward(const float* P, float v, float gout, float* gp) {
+  const float* m = P;
+  const float* b = P + 33;
+  const float* f = P + 46;
+  float a[4][3], th[4][3], l[4][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    a[0][i] = m[i] * v + b[i];
+    th[0][i] = tanhf(a[0][i]);
+    l[0][i] = a[0][i] + f[i] * th[0][i];
+  }
+#pragma unroll
+  for (int k = 1; k <= 3; ++k) {
+    const float* mk = m + 3 + (k - 1) * 9;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      a[k][i] = mk[i * 3 + 0] * l[k - 1][0] + mk[i * 3 + 1] * l[k - 1][1] + mk[i * 3 + 2] * l[k - 1][2] + b[3 * k + i];
+      th[k][i] = tanhf(a[k][i]);
+      l[k][i] = a[k][i] + f[3 * k + i] * th[k][i];
+    }
+  }
+  float dl[3], da[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { gp[30 + j] += gout * l[3][j]; dl[j] = gout * m[30 + j]; }
+  gp[33 + 12] += gout;
+#pragma unroll
+  for (int k = 3; k >= 1; --k) {
+    const float* mk = m + 3 + (k - 1) * 9;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      da[i] = dl[i] * (1.f + f[3 * k + i] * (1.f - th[k][i] * th[k][i]));
+      gp[46 + 3 * k + i] += dl[i] * th[k][i];
+      gp[33 + 3 * k + i] += da[i];
+    }
+    float nd[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        gp[3 + (k - 1) * 9 + i * 3 + j] += da[i] * l[k - 1][j];
+        nd[j] += da[i] * mk[i * 3 + j];
+      }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dl[j] = nd[j];
+  }
+  float dv = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float d0 = dl[i] * (1.f + f[i] * (1.f - th[0][i] * th[0][i]));
+    gp[46 + i] += dl[i] * th[0][i];
+    gp[33 + i] += d0;
+    gp[i] += d0 * v;
+    dv += d0 * m[i];
+  }
+  return dv;
+}
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+// one workgroup per channel: dz += gscale * d bits / d z, dparams[c][:] += gscale * d bits / d params (bits = -log2 lik)
+__global__ __launch_bounds__(256) void eb_backward_kernel(FMap z, const float* params, FMap noise, float gscale, FMap dz, float* dparams) {
+  __shared__ float red[4][EBP];
+  const int c = blockIdx.x;
+  const float* P = params + (long)c * EBP;
+  const long npix = (long)z.H * z.W;
+  const long count = npix * z.N;
+  float gp[EBP];
+#pragma unroll
+  for (int i = 0; i < EBP; ++i) gp[i] = 0.f;
+  for (long e = threadIdx.x; e < count; e += 256) {
+    const int n = (int)(e / npix);
+    const long pix = e % npix;
+    const float zv = reinterpret_cast<const float*>(z.p)[(long)n * z.sn + pix * z.sp + c];
+    const float v = zv + reinterpret_cast<const float*>(noise.p)[(long)n * noise.sn + pix * noise.sp + c];
+    // forward values (pointwise.hip::eb_forward_kernel); the sign is a constant of the backward pass
+    const float lo = eb_logits(P, v - 0.5f), up = eb_logits(P, v + 0.5f);
+    const float ssum = lo + up;
+    const float sign = ssum > 0.f ? -1.f : (ssum < 0.f ? 1.f : 0.f);
+    const float su = sigm(sign * up), sl = sigm(sign * lo);
+    const float diff = su - sl;
+    const float lik = fabsf(diff);
+    float dv = 0.f;
+    if (lik > 1e-9f) {
+      const float dlik = -gscale / (lik * 0.69314718055994531f);           // d(-log2 lik)
+      const float sd = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+      const float gup = dlik * sd * su * (1.f - su) * sign;
+      const float glo = -dlik * sd * sl * (1.f - sl) * sign;
+      dv = eb_logits_backward(P, v + 0.5f, gup, gp) + eb_logits_backward(P, v - 0.5f, glo, gp);
+    }
+    reinterpret_cast<float*>(dz.p)[(long)n * dz.sn + pix * dz.sp + c] += dv;
+  }
+  // reduce the 59 parameter gradients over the workgroup (wave shuffles, then 4 waves in LDS; fixed order)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < EBP; ++i) {
+    float v = gp[i];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < EBP) dparams[(long)c * EBP + threadIdx.x] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// Gaussian conditional with additive noise: bits = -log2 max(Phi((.5 - v)/s) - Phi((-.5 - v)/s), 1e-9), v = |y + noise - mean|,
+// s = max(scale, 0.11): dy, dmean (= -dy), dscale (zero below the bound, as the oracle's plain max)
+__global__ void gc_backward_kernel(FMap y, FMap gp, FMap noise, float gscale, FMap dy, FMap dgp) {
+  const long npix = (long)y.H * y.W;
+  const long total = npix * y.C * y.N;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % y.C);
+  const long t = i / y.C;
+  const long pix = t % npix;
+  const int n = (int)(t / npix);
+  const float yv = reinterpret_cast<const float*>(y.p)[(long)n * y.sn + pix * y.sp + c];
+  const float* g = reinterpret_cast<const float*>(gp.p) + (long)n * gp.sn + pix * gp.sp;
+  const float sc = g[c], mean = g[y.C + c];
+  const float s = fmaxf(sc, 0.11f);
+  const float u = yv + reinterpret_cast<const float*>(noise.p)[(long)n * noise.sn + pix * noise.sp + c] - mean;
+  const float v = fabsf(u);
+  const float k = 0.70710678118654752440f;
+  const float a = (0.5f - v) / s, b = (-0.5f - v) / s;
+  const float lik = 0.5f * erfcf(-k * a) - 0.5f * erfcf(-k * b);
+  if (!(lik > 1e-9f)) return;
+  const float inv_sqrt_2pi = 0.39894228040143267794f;
+  const float pa = inv_sqrt_2pi * expf(-0.5f * a * a), pb = inv_sqrt_2pi * expf(-0.5f * b * b);
+  const float dlik = -gscale / (lik * 0.69314718055994531f);
+  const float dv = dlik * (pb - pa) / s;
+  const float du = dv * (u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f));
+  reinterpret_cast<float*>(dy.p)[(long)n * dy.sn + pix * dy.sp + c] += du;
+  float* dg = reinterpret_cast<float*>(dgp.p) + (long)n * dgp.sn + pix * dgp.sp;
+  dg[y.C + c] -= du;
+  if (sc > 0.11f) dg[c] += dlik * (b * pb - a * pa) / s;
+}
+
 }  // namespace
 
 extern "C" int tdvc_act_backward(const tdvc_fmap* g, const tdvc_fmap* y, const tdvc_fmap* res, int act, float slope, const tdvc_fmap* out, void* stream) {
@@ -732,4 +871,20 @@ extern "C" int tdvc_mul2_accumulate(const tdvc_fmap* dx, const tdvc_fmap* x, con
   const long total = (long)dx->N * dx->H * dx->W * (dx->C / 8);
   hipLaunchKernelGGL(mul2_accumulate_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*dx), to_dev(*x), to_dev(*t));
   return tdvc_launch_status("tdvc_mul2_accumulate");
+}
+
+extern "C" int tdvc_eb_backward(const tdvc_fmap* z, const float* params, const tdvc_fmap* noise, float gscale, const tdvc_fmap* dz, float* dparams, void* stream) {
+  TDVC_CHECK(z && params && noise && dz && dparams && fmap_ok32(*z) && fmap_ok32(*noise) && fmap_ok32(*dz) && same_geom(*z, *noise) && same_geom(*z, *dz) &&
+                 noise->C >= z->C && dz->C >= z->C, "tdvc_eb_backward: bad arguments");
+  hipLaunchKernelGGL(eb_backward_kernel, dim3(z->C), dim3(256), 0, ST(stream), to_dev(*z), params, to_dev(*noise), gscale, to_dev(*dz), dparams);
+  return tdvc_launch_status("tdvc_eb_backward");
+}
+
+extern "C" int tdvc_gc_backward(const tdvc_fmap* y, const tdvc_fmap* gp, const tdvc_fmap* noise, float gscale, const tdvc_fmap* dy, const tdvc_fmap* dgp, void* stream) {
+  TDVC_CHECK(y && gp && noise && dy && dgp && fmap_ok32(*y) && fmap_ok32(*gp) && fmap_ok32(*noise) && fmap_ok32(*dy) && fmap_ok32(*dgp) && same_geom(*y, *gp) &&
+                 same_geom(*y, *noise) && same_geom(*y, *dy) && same_geom(*y, *dgp) && gp->C >= 2 * y->C && dgp->C >= 2 * y->C && dy->C >= y->C,
+             "tdvc_gc_backward: bad arguments");
+  const long total = (long)y->N * y->H * y->W * y->C;
+  hipLaunchKernelGGL(gc_backward_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*y), to_dev(*gp), to_dev(*noise), gscale, to_dev(*dy), to_dev(*dgp));
+  return tdvc_launch_status("tdvc_gc_backward");
 }

@@ -445,33 +445,6 @@ __global__ __launch_bounds__(256) void match_gather_kernel(FMap fin, FMap fref, 
 }
 
 // ------------------------------------------------------------------ entropy model
-constexpr int EB_NP = 59;   // floats per channel, see tdvc_amd/entropy.py::pack_eb_params
-
-__device__ __forceinline__ float eb_logits(const float* P, float v) {
-  // filters (1,3,3,3,3,1): m0[3], m1..m3[9], m4[3] | b0..b3[3], b4[1] | f0..f3[3] | median
-  const float* m = P;
-  const float* b = P + 33;
-  const float* f = P + 46;
-  float l[3], t[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    l[i] = m[i] * v + b[i];
-    l[i] += f[i] * tanhf(l[i]);
-  }
-#pragma unroll
-  for (int k = 1; k <= 3; ++k) {
-    const float* mk = m + 3 + (k - 1) * 9;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      t[i] = mk[i * 3 + 0] * l[0] + mk[i * 3 + 1] * l[1] + mk[i * 3 + 2] * l[2] + b[3 * k + i];
-      t[i] += f[3 * k + i] * tanhf(t[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) l[i] = t[i];
-  }
-  return m[30] * l[0] + m[31] * l[1] + m[32] * l[2] + b[12];
-}
-
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 __global__ __launch_bounds__(256) void eb_forward_kernel(FMap z, const float* params, FMap noise, FMap z_hat, float* partial) {

@@ -178,18 +178,36 @@ class EntropyBottleneck(nn.Module, PackCache):
         self.quantiles = nn.Parameter(q.repeat(channels, 1, 1))
         self.register_buffer("target", torch.Tensor([np.log(2 / self.tail_mass - 1)]))
 
-    def packed_params(self) -> torch.Tensor:
+    def _packed_tensor(self) -> torch.Tensor:
         """[C][59] fp32: softplus(matrix0..4) | bias0..4 | tanh(factor0..3) | median"""
+        C_ = self.channels
+        parts = [F.softplus(getattr(self, f"_matrix{i}")).reshape(C_, -1) for i in range(5)]
+        parts += [getattr(self, f"_bias{i}").reshape(C_, -1) for i in range(5)]
+        parts += [torch.tanh(getattr(self, f"_factor{i}")).reshape(C_, -1) for i in range(4)]
+        parts += [self.quantiles[:, 0, 1:2]]
+        p = torch.cat(parts, 1).float().contiguous()
+        assert p.shape == (C_, 59)
+        return p
+
+    def packed_params(self) -> torch.Tensor:
         def build():
-            C_ = self.channels
-            parts = [F.softplus(getattr(self, f"_matrix{i}").detach()).reshape(C_, -1) for i in range(5)]
-            parts += [getattr(self, f"_bias{i}").detach().reshape(C_, -1) for i in range(5)]
-            parts += [torch.tanh(getattr(self, f"_factor{i}").detach()).reshape(C_, -1) for i in range(4)]
-            parts += [self.quantiles.detach()[:, 0, 1:2]]
-            p = torch.cat(parts, 1).float().contiguous()
-            assert p.shape == (C_, 59)
+            with torch.no_grad():
+                p = self._packed_tensor()
+            p.owner = self
             return p
         return self._pk("eb", build)
+
+    def refresh_packed(self):
+        self.__dict__.get("_packed", {}).pop("eb", None)
+
+    def accumulate_param_grads(self, dpacked: torch.Tensor):
+        """chain rule through softplus / tanh (parameter space, 128 x 59 values: plain autograd); the median column
+        (quantiles) only receives the auxiliary loss"""
+        with torch.enable_grad():
+            p = self._packed_tensor()
+            d = dpacked.clone()
+            d[:, 58] = 0.0
+            torch.autograd.backward([p], [d])
 
     def logits_cumulative(self, x, stop_gradient):
         for i in range(len(self.filters) + 1):
@@ -296,11 +314,17 @@ class Cheng2020Anchor(nn.Module, PackCache):
 
     def ctx_conv(self) -> ops.PackedConv:
         cp = self.context_prediction
-        return self._pk("ctx", lambda: ops.pack_conv(cp.weight, cp.bias, stride=1, pad=2, taps=cp.live_taps(),
-                                                     device=cp.weight.device))
+
+        def build():
+            pc = ops.pack_conv(cp.weight, cp.bias, stride=1, pad=2, taps=cp.live_taps(), device=cp.weight.device)
+            # compressai zeroes the masked taps in the forward (`weight.data *= mask`) but autograd still fills their
+            # gradient, and the reference clips the norm over ALL of it (tools/train.py:147)
+            pc.orig["wgrad_taps"] = [(dy, dx) for dy in range(5) for dx in range(5)]
+            return pc
+        return self._pk("ctx", build)
 
     # -- forward (`main/model/pnet.py:34,58`) ------------------------------------------------
-    def run(self, x: FM, training: bool, out: FM | None = None, res: FM | None = None, trace=None):
+    def run(self, x: FM, training: bool, out: FM | None = None, res: FM | None = None, trace=None, noise=None):
         """x: (B,H,W,64) fp16.  Returns (x_hat FM [+res], bits tensor (2,) float64 = [y, z])."""
         dev = x.t.device
         y32, y16 = self.run_g_a(x)
@@ -308,17 +332,21 @@ class Cheng2020Anchor(nn.Module, PackCache):
         B, h, w, M = y32.N, y32.H, y32.W, self.M
         bits = torch.zeros(2, dtype=torch.float64, device=dev)
         z_hat = FM.empty(z.N, z.H, z.W, z.C, device=dev)
-        nz = ny = None
+        nz = ny = nl = None
         if training:
-            nz = FM(torch.rand((z.N, z.H, z.W, z.C), device=dev) - 0.5)
-            ny = FM(torch.rand((B, h, w, M), device=dev) - 0.5)
+            # three independent U(-1/2, 1/2) draws, as compressai: factorised prior, y_hat, Gaussian likelihood
+            # (`noise`: test hook, dict of fp32 FMs {"z", "y", "y_lik"})
+            noise = noise or {}
+            nz = noise.get("z") or FM(torch.rand((z.N, z.H, z.W, z.C), device=dev) - 0.5)
+            ny = noise.get("y") or FM(torch.rand((B, h, w, M), device=dev) - 0.5)
+            nl = noise.get("y_lik") or FM(torch.rand((B, h, w, M), device=dev) - 0.5)
         ops.eb_forward(z, self.entropy_bottleneck.packed_params(), z_hat, bits[1:2], noise=nz)
         pcat = FM.empty(B, h, w, 4 * M, device=dev)             # [h_s params | context]
         self.run_h_s(z_hat, out=pcat.ch(0, 2 * M))
         y_hat = ops.quantize(y32, FM.empty(B, h, w, M, device=dev), noise=ny)
         ops.conv(y_hat, self.ctx_conv(), out=pcat.ch(2 * M, 2 * M))
         gp = self.run_entropy_parameters(pcat)
-        ops.gc_forward(y32, gp, bits[0:1], noise=ny)
+        ops.gc_forward(y32, gp, bits[0:1], noise=nl)
         x_hat = self.run_g_s(y_hat, out=out, res=res)
         if trace is not None:
             trace.update(y=y32, z=z, z_hat=z_hat, y_hat=y_hat, gp=gp)

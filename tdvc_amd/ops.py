@@ -351,22 +351,24 @@ def conv_dgrad(pc: PackedConv, g: FM, dx: FM, accumulate=True) -> FM:
 
 
 def conv_wgrad(pc: PackedConv, g: FM, x: FM, dw: torch.Tensor, scale=1.0, square_x=False) -> None:
-    """dW += scale * dL/dW (fp32, the parameter's own layout); `g` as in conv_dgrad"""
+    """dW += scale * dL/dW (fp32, the parameter's own layout); `g` as in conv_dgrad.  `pc.orig["wgrad_taps"]` widens
+    the tap list beyond the forward's (masked convs: the reference's autograd also fills the masked taps)."""
     o = pc.orig
+    taps = o.get("wgrad_taps") or o["taps"]
     tb = pc.__dict__.get("_wg_tables")
     if tb is None:                               # plain-geometry tables (also for layers that RUN in space-to-depth form)
-        tb = convpack.forward_tables(pc.layout, cin_pad=x.C, taps=o["taps"], pad=o["pad"], ck=8, shuffle=pc.shuffle, cin_perm=o["cin_perm"],
+        tb = convpack.forward_tables(pc.layout, cin_pad=x.C, taps=taps, pad=o["pad"], ck=8, shuffle=pc.shuffle, cin_perm=o["cin_perm"],
                                      device=pc.w.device)
         pc.__dict__["_wg_tables"] = tb
     assert dw.is_cuda and dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == pc.wsrc.numel()
     lib = L.lib()
     Ho, Wo = g.H, g.W
-    nwork = lib.tdvc_conv_wgrad_work_floats(pc.cout, x.C, len(o["taps"]), x.N, Ho, Wo)
+    nwork = lib.tdvc_conv_wgrad_work_floats(pc.cout, x.C, len(taps), x.N, Ho, Wo)
     work = torch.empty((nwork,), dtype=torch.float32, device=dw.device)
-    dy = (C.c_int8 * len(o["taps"]))(*[t[0] for t in o["taps"]])
-    dxs = (C.c_int8 * len(o["taps"]))(*[t[1] for t in o["taps"]])
+    dy = (C.c_int8 * len(taps))(*[t[0] for t in taps])
+    dxs = (C.c_int8 * len(taps))(*[t[1] for t in taps])
     dg, dxd = g.desc(), x.desc()
-    L.check(lib.tdvc_conv_wgrad(C.byref(dg), C.byref(dxd), pc.cout, o["kh"], o["kw"], o["stride"], o["pad"], len(o["taps"]), dy, dxs,
+    L.check(lib.tdvc_conv_wgrad(C.byref(dg), C.byref(dxd), pc.cout, o["kh"], o["kw"], o["stride"], o["pad"], len(taps), dy, dxs,
                                 tb.row_off.data_ptr(), tb.chan_off.data_ptr(), tb.tap_off.data_ptr(), int(square_x), scale, dw.data_ptr(),
                                 work.data_ptr(), nwork, _stream()), "conv_wgrad")
 
@@ -619,6 +621,17 @@ def eb_forward(z: FM, params: torch.Tensor, z_hat: FM, bits_out: torch.Tensor, n
     dn = noise.desc() if noise is not None else None
     L.check(L.lib().tdvc_eb_forward(C.byref(dz), params.data_ptr(), C.byref(dn) if dn is not None else None, C.byref(dh),
                                     bits_out.data_ptr(), partial.data_ptr(), cap, _stream()), "eb_forward")
+    _rec("eb_forward", z, params, z_hat, noise)
+
+
+def eb_backward(z: FM, params: torch.Tensor, noise: FM, gscale: float, dz: FM, dparams: torch.Tensor) -> None:
+    d1, d2, d3 = z.desc(), noise.desc(), dz.desc()
+    L.check(L.lib().tdvc_eb_backward(C.byref(d1), params.data_ptr(), C.byref(d2), gscale, C.byref(d3), dparams.data_ptr(), _stream()), "eb_backward")
+
+
+def gc_backward(y: FM, gp: FM, noise: FM, gscale: float, dy: FM, dgp: FM) -> None:
+    d1, d2, d3, d4, d5 = y.desc(), gp.desc(), noise.desc(), dy.desc(), dgp.desc()
+    L.check(L.lib().tdvc_gc_backward(C.byref(d1), C.byref(d2), C.byref(d3), gscale, C.byref(d4), C.byref(d5), _stream()), "gc_backward")
 
 
 def gc_forward(y: FM, gp: FM, bits_out: torch.Tensor, noise: FM | None = None):
@@ -629,12 +642,14 @@ def gc_forward(y: FM, gp: FM, bits_out: torch.Tensor, noise: FM | None = None):
     dn = noise.desc() if noise is not None else None
     L.check(L.lib().tdvc_gc_forward(C.byref(dy), C.byref(dg), C.byref(dn) if dn is not None else None,
                                     bits_out.data_ptr(), partial.data_ptr(), cap, _stream()), "gc_forward")
+    _rec("gc_forward", y, gp, noise)
 
 
 def quantize(y: FM, out: FM, noise: FM | None = None) -> FM:
     dy, do = y.desc(), out.desc()
     dn = noise.desc() if noise is not None else None
     L.check(L.lib().tdvc_quantize(C.byref(dy), C.byref(dn) if dn is not None else None, C.byref(do), _stream()), "quantize")
+    _rec("quantize", y, out, noise)
     return out
 
 

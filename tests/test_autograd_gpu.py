@@ -322,3 +322,41 @@ def test_coder_blocks_backward(report):
     e2 = _rel(fm_to_cpu(out2), y2)
     report(f"coder blocks forward after update + repack: rel L2 err {e2:.3e}")
     assert e2 < 5e-3
+
+
+def test_coder_backward(report):
+    """a whole Cheng2020Anchor coder in training mode with injected noise: transforms, hyperprior, masked context conv,
+    entropy parameters, factorised-prior and Gaussian rate terms (gradients of the bit counts), reparametrisations"""
+    from oracle.tdvc_ref import coder as oc
+    from tdvc_amd import autograd, ops
+    from tdvc_amd.model import coder as dc
+    dev, ref = _pair(dc.ResCoder, oc.ResCoder, 128)
+    dev.train()
+    ref.train()
+    B, H, W = 1, 64, 128
+    g = torch.Generator().manual_seed(61)
+    x = rnd16(torch.randn(B, 64, H, W, generator=g) * 0.5).requires_grad_()
+    u = lambda *s: torch.rand(*s, generator=g) - 0.5
+    noise = {"z": u(B, 128, H // 64, W // 64), "y": u(B, 128, H // 16, W // 16), "y_lik": u(B, 128, H // 16, W // 16)}
+    wgt = randn(B, 64, H, W, seed=62)
+    kappa = 50.0                                               # weight of the rate term relative to the distortion surrogate
+    o = ref(x, noise)
+    bits = sum((-torch.log2(l)).sum() for l in o["likelihoods"].values())
+    ((o["x_hat"] * wgt).sum() + kappa * bits).backward()
+    with autograd.record() as tape:
+        xf = to_fm(x.detach(), ops)
+        nf = {k: to_fm(v, ops, Cpad=128, dtype=torch.float32) for k, v in noise.items()}
+        x_hat, dbits = dev.run(xf, training=True, noise=nf)
+        ops.copy_cast(to_fm(wgt, ops), tape.grad(x_hat))
+        tape.rate_grad = kappa
+        tape.backward()
+        gx = fm_to_cpu(tape.grad(xf))
+    assert _rel(fm_to_cpu(x_hat), o["x_hat"].detach()) < 5e-3
+    bref = torch.stack([(-torch.log2(o["likelihoods"][k])).sum() for k in ("y", "z")]).double()
+    eb = float(((dbits.cpu() - bref).abs() / bref).max())
+    report(f"coder training-mode bits (y, z): device {dbits.cpu().tolist()} oracle {bref.tolist()} rel err {eb:.3e}")
+    assert eb < 5e-3
+    e = _rel(gx, x.grad)
+    report(f"coder dx: rel L2 err {e:.3e}")
+    assert e < 5e-2
+    _check_param_grads(dev, ref, report, 8e-2, "coder")
