@@ -32,13 +32,14 @@ class VideoCompressor(nn.Module):
         self.loopfilter = FeatureFix()      # in-loop filter (sic, `pnet.py:23`)
         self.mcfilter = LoopFilter()        # multi-frame fusion (sic, `pnet.py:24`)
 
-    def forward(self, input_image, refer_frames, enabled_amp=False, is_compress=False, trace=None):
+    def forward(self, input_image, refer_frames, enabled_amp=False, is_compress=False, trace=None, noise=None):
+        noise = noise or {}            # test hook: {"mv": {...}, "res": {...}} replaces the coders' training-mode draws
         ref = refer_frames[:, -1].clone()
         f_cur = self.extra_fea(input_image)
         f_ref = self.extra_fea(ref)
         estmv = self.motion_est(f_cur, f_ref, input_image, ref)
 
-        mv = self.mvCoder(estmv.float())
+        mv = self.mvCoder(estmv.float(), noise.get("mv"))
         mv_aux = self.mvCoder.aux_loss()
         N, _, H, W = input_image.shape
         npx = N * H * W
@@ -53,7 +54,7 @@ class VideoCompressor(nn.Module):
         pred = self.mcfilter(pred1, refer_frames)
         resid = f_cur - pred
 
-        rs = self.resCoder(resid.float())
+        rs = self.resCoder(resid.float(), noise.get("res"))
         res_aux = self.resCoder.aux_loss()
         bpp_res = bpp_from_likelihoods(rs["likelihoods"], npx)
         if is_compress:

@@ -45,11 +45,12 @@ class VideoCompressor(nn.Module):
         return super()._apply(fn, *a, **kw)
 
     # ----------------------------------------------------------------------------------------
-    def forward(self, input_image, refer_frames, enabled_amp=True, is_compress=False, trace=None):
+    def forward(self, input_image, refer_frames, enabled_amp=True, is_compress=False, trace=None, noise=None):
+        noise = noise or {}            # test hook: {"mv": {...}, "res": {...}} of fp32 FMs replaces the coders' training-mode draws
         if not (input_image.is_cuda and refer_frames.is_cuda):
             raise RuntimeError("tdvc_amd.VideoCompressor runs on a HIP device only (no CPU fallback)")
-        training = self.training       # noise quantisation, scale-8 matching, 5-tuple return (pnet.py:80-83); the
-        # outputs carry no autograd graph yet: the backward kernels are not built
+        training = self.training       # noise quantisation, scale-8 matching, 5-tuple return (pnet.py:80-83); gradients
+        # come from the tape of tdvc_amd/autograd.py (`with autograd.record(): model(...)`), not from torch.autograd
         B, _, H, W = input_image.shape
         if H % 64 or W % 64:
             raise RuntimeError(f"input must be padded to a multiple of 64 (got {H}x{W}); see tools/predict.py:51-53")
@@ -64,6 +65,9 @@ class VideoCompressor(nn.Module):
             ref32 = ops.from_nchw(last, Cpad=4, dtype=torch.float32)
             ref8 = ops.from_nchw(last, Cpad=8)
             iframe8 = ops.from_nchw(refer_frames[:, 0].float(), Cpad=8)
+            if ops.TAPE is not None:                                     # network inputs carry no gradient
+                for t in (cur32, cur8, refs8, ref32, ref8, iframe8):
+                    ops.TAPE.mark_input(t)
 
             feats = FM.empty(B, H, W, 192, device=dev)                   # [f_cur | f_ref | dcn_out]
             npx_ = float(B * H * W)
@@ -72,7 +76,7 @@ class VideoCompressor(nn.Module):
             estmv = self.motion_est.run(feats, cur32, ref32)
 
             tr_mv = {} if trace is not None else None
-            mv_hat, mv_bits = self.mvCoder.run(estmv, training=training, trace=tr_mv)
+            mv_hat, mv_bits = self.mvCoder.run(estmv, training=training, trace=tr_mv, noise=noise.get("mv"))
             coded = {}
             if is_compress:                                      # pnet.py:45-49
                 self.mvCoder.update(force=True)
@@ -85,7 +89,7 @@ class VideoCompressor(nn.Module):
             resid = ops.scale_act_res(f_cur, FM.empty(B, H, W, 64, device=dev), res=pred, res_sign=-1.0)
 
             tr_res = {} if trace is not None else None
-            recon_f, res_bits = self.resCoder.run(resid, training=training, res=pred, trace=tr_res)
+            recon_f, res_bits = self.resCoder.run(resid, training=training, res=pred, trace=tr_res, noise=noise.get("res"))
             if is_compress:                                      # pnet.py:69-73
                 self.resCoder.update(force=True)
                 coded["res"] = self.resCoder.compress(resid)

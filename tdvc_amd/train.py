@@ -1,0 +1,112 @@
+"""One optimisation step of the TDVC P-frame model on MI355X (counterpart of `tools/train.py:122-159`).
+
+    rd_loss = lambda * MSE(recon, input) + bpp_res + bpp_mv          (train.py:136-140)
+    optimizer.zero_grad(); aux_optimizer.zero_grad()
+    scaler.scale(rd_loss).backward(); scaler.unscale_(optimizer)
+    clip_grad_norm_(model.parameters(), 2); scaler.step(optimizer); scaler.update()
+    aux_loss.backward(); aux_optimizer.step()                        (train.py:142-152)
+
+The forward and backward run in the HIP kernels (forward under `autograd.record`, backward = the tape); the loss
+scale is a constant (the weight-gradient kernels un-scale, so there is no separate `unscale_` pass), gradient
+clipping and Adam are torch's device-side optimizer utilities, the auxiliary (quantile) loss is parameter-space
+autograd.  With several ranks the parameter gradients are averaged by RCCL before clipping, so every rank clips
+and steps identically; `GradBuckets` packs them into a few flat buffers.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import autograd, ops
+from .synth import split_optim_params
+
+
+def refresh_packed(model: torch.nn.Module) -> None:
+    """after an optimizer step: every packed layer follows its (in-place updated) parameters"""
+    for m in model.modules():
+        if hasattr(m, "refresh_packed"):
+            m.refresh_packed()                       # GDN (effective gamma / beta), EntropyBottleneck (packed table)
+            continue
+        for pc in m.__dict__.get("_packed", {}).values():
+            if isinstance(pc, ops.PackedConv):
+                pc.repack()
+
+
+class GradBuckets:
+    """Flat fp32 buckets over the parameter gradients: `param.grad` tensors become views into a few large buffers,
+    so the data-parallel exchange is a handful of large all-reduces (xGMI rings are per-link bound: few, large
+    messages) and `zero_grad` is one memset per bucket."""
+
+    def __init__(self, params, bucket_bytes: int = 64 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets = []
+        cur, cur_n = [], 0
+        for p in self.params:
+            if cur and (cur_n + p.numel()) * 4 > bucket_bytes:
+                self._close(cur, cur_n)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            self._close(cur, cur_n)
+
+    def _close(self, ps, n):
+        flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
+        off = 0
+        for p in ps:
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.buckets.append(flat)
+
+    def zero(self):
+        for b in self.buckets:
+            b.zero_()
+
+    def all_reduce_mean(self):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        world = dist.get_world_size()
+        works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True) for b in self.buckets]
+        for w, b in zip(works, self.buckets):
+            w.wait()
+            b.mul_(1.0 / world)
+
+
+class TrainStep:
+    def __init__(self, model, train_lambda: float = 2048.0, lr: float = 1e-4, loss_scale: float = 1024.0, clip: float = 2.0):
+        self.model = model
+        self.lam = float(train_lambda)
+        self.loss_scale = float(loss_scale)
+        self.clip = float(clip)
+        main, aux = split_optim_params(model)
+        named = dict(model.named_parameters())
+        self.main_params = [named[n] for n in main]
+        self.aux_params = [named[n] for n in aux]
+        self.buckets = GradBuckets(self.main_params)
+        self.optimizer = torch.optim.Adam(self.main_params, lr=lr)
+        self.aux_optimizer = torch.optim.Adam(self.aux_params, lr=10 * lr)          # utils.py:110-112
+
+    def __call__(self, input_image: torch.Tensor, refer_frames: torch.Tensor) -> dict:
+        model = self.model
+        model.train()
+        B, _, H, W = input_image.shape
+        self.buckets.zero()
+        for p in self.aux_params:
+            p.grad = None
+        with autograd.record(self.loss_scale) as tape:
+            recon, bpp_res, bpp_mv, aux_mv, aux_res = model(input_image, refer_frames, True)
+            diff = recon - input_image.float()
+            mse = (diff * diff).mean()
+            # d(lambda * MSE)/d recon, scaled; the rate terms are seeded through tape.rate_grad
+            tape.grad_tensor(recon).copy_(diff * (2.0 * self.lam * self.loss_scale / diff.numel()))
+            tape.rate_grad = 1.0 / float(B * H * W)
+            tape.backward()
+        self.buckets.all_reduce_mean()
+        gnorm = torch.nn.utils.clip_grad_norm_(self.main_params, self.clip)
+        self.optimizer.step()
+        aux = aux_mv + aux_res
+        aux.backward()
+        self.aux_optimizer.step()
+        refresh_packed(model)
+        return dict(rd_loss=float(self.lam * mse + bpp_res.mean() + bpp_mv.mean()), mse=float(mse), bpp_res=float(bpp_res.mean()),
+                    bpp_mv=float(bpp_mv.mean()), aux_loss=float(aux), grad_norm=float(gnorm))

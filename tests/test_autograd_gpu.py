@@ -360,3 +360,67 @@ def test_coder_backward(report):
     report(f"coder dx: rel L2 err {e:.3e}")
     assert e < 5e-2
     _check_param_grads(dev, ref, report, 8e-2, "coder")
+
+
+def test_full_model_backward_and_steps(report):
+    """the whole VideoCompressor: rd_loss = lambda * MSE + bpp_res + bpp_mv (tools/train.py:136-140) with injected noise;
+    every parameter gradient against the oracle's autograd, then three optimisation steps of TrainStep"""
+    from oracle.tdvc_ref.codec import VideoCompressor as RefVC
+    from tdvc_amd import autograd, ops, synth
+    from tdvc_amd.model.pnet import VideoCompressor
+    from tdvc_amd.train import TrainStep
+    ref = RefVC()
+    synth.fill_parameters(ref)
+    dev = VideoCompressor()
+    dev.load_state_dict(ref.state_dict())
+    dev = dev.cuda()
+    dev.train()
+    ref.train()
+    B, H, W, lam = 1, 64, 64, 2048.0
+    gop = synth.make_gop(1234, 7, H, W)
+    frames = gop.float()
+    x = frames[3:4]
+    refs = torch.stack([frames[0], frames[0], frames[1], frames[2]]).unsqueeze(0)
+    g = torch.Generator().manual_seed(71)
+    u = lambda *s: torch.rand(*s, generator=g) - 0.5
+    mk = lambda: {"z": u(B, 128, H // 64, W // 64), "y": u(B, 128, H // 16, W // 16), "y_lik": u(B, 128, H // 16, W // 16)}
+    noise = {"mv": mk(), "res": mk()}
+    recon, bpp_res, bpp_mv, _, _ = ref(x, refs, noise=noise)
+    loss = lam * torch.nn.functional.mse_loss(recon, x) + bpp_res.mean() + bpp_mv.mean()
+    loss.backward()
+    with autograd.record() as tape:
+        nf = {k: {kk: to_fm(v, ops, Cpad=128, dtype=torch.float32) for kk, v in d.items()} for k, d in noise.items()}
+        r, br, bm, _, _ = dev(x.cuda(), refs.cuda(), True, noise=nf)
+        diff = r - x.cuda()
+        tape.grad_tensor(r).copy_(diff * (2.0 * lam / diff.numel()))
+        tape.rate_grad = 1.0 / float(B * H * W)
+        tape.backward()
+    dl = float(lam * (diff * diff).mean() + br.mean() + bm.mean())
+    report(f"full model rd_loss: device {dl:.5f} oracle {float(loss):.5f}")
+    assert abs(dl - float(loss)) < 2e-2 * abs(float(loss))
+    errs = []
+    for (k, p), (k2, q) in zip(dev.named_parameters(), ref.named_parameters()):
+        assert k == k2
+        if q.grad is None or float(q.grad.norm()) == 0.0 or k.endswith(".quantiles"):
+            continue
+        assert p.grad is not None, k
+        errs.append((_rel(p.grad.cpu(), q.grad), k))
+    errs.sort()
+    worst = errs[-5:]
+    report(f"full model: {len(errs)} parameter gradients, rel L2 err median {errs[len(errs) // 2][0]:.3e}, 90% {errs[int(0.9 * len(errs))][0]:.3e}, worst {worst}")
+    gd = torch.cat([p.grad.reshape(-1).cpu() for (k, p), (_, q) in zip(dev.named_parameters(), ref.named_parameters())
+                    if q.grad is not None and not k.endswith(".quantiles")])
+    gr = torch.cat([q.grad.reshape(-1) for (k, _), (_, q) in zip(dev.named_parameters(), ref.named_parameters())
+                    if q.grad is not None and not k.endswith(".quantiles")])
+    tot = _rel(gd, gr)
+    report(f"full model: whole-gradient rel L2 err {tot:.3e}, norms device {float(gd.norm()):.4e} oracle {float(gr.norm()):.4e}")
+    assert tot < 5e-2 and errs[int(0.9 * len(errs))][0] < 0.15
+    # three optimisation steps: finite, and the loss moves down on a fixed sample
+    for p in dev.parameters():
+        p.grad = None
+    step = TrainStep(dev, train_lambda=lam, lr=1e-4, loss_scale=128.0)
+    torch.manual_seed(0)
+    logs = [step(x.cuda(), refs.cuda()) for _ in range(4)]
+    report("full model train steps: " + "; ".join(f"rd {l['rd_loss']:.4f} |g| {l['grad_norm']:.3e}" for l in logs))
+    assert all(l["rd_loss"] == l["rd_loss"] and l["grad_norm"] == l["grad_norm"] for l in logs)
+    assert logs[-1]["rd_loss"] < logs[0]["rd_loss"]
