@@ -109,4 +109,4 @@ class TrainStep:
         self.aux_optimizer.step()
         refresh_packed(model)
         return dict(rd_loss=float(self.lam * mse + bpp_res.mean() + bpp_mv.mean()), mse=float(mse), bpp_res=float(bpp_res.mean()),
-                    bpp_mv=float(bpp_mv.mean()), aux_loss=float(aux), grad_norm=float(gnorm))
+                    bpp_mv=float(bpp_mv.mean()), aux_loss=float(aux.detach()), grad_norm=float(gnorm))

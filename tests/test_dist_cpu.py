@@ -46,3 +46,40 @@ def test_gop_sharding_and_stat_gather():
     assert mine == [0, 2, 4, 6]
     assert len(allstats) == 14 and [s["gop"] for s in allstats] == sorted(s["gop"] for s in allstats)
     assert {s["gop"] for s in allstats} == set(range(7))
+
+
+def _grad_worker(rank, world, port, q):
+    """data-parallel training exchange: every rank fills its gradient buckets with rank-dependent values; after
+    GradBuckets.all_reduce_mean() all ranks hold the mean, and param.grad are still views of the flat buckets"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tdvc_amd.train import GradBuckets
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(*s)) for s in [(64, 64, 3, 3), (64,), (128, 64, 1, 1), (7,), (300, 300)]]
+    gb = GradBuckets(params, bucket_bytes=200_000)           # forces several buckets
+    for i, p in enumerate(params):
+        p.grad.fill_(float(rank + 1) * (i + 1))
+    gb.all_reduce_mean()
+    mean = sum(range(1, world + 1)) / world
+    ok = all(torch.allclose(p.grad, torch.full_like(p, mean * (i + 1))) for i, p in enumerate(params))
+    views = all(p.grad.untyped_storage().data_ptr() in {b.untyped_storage().data_ptr() for b in gb.buckets} for p in params)
+    gb.zero()
+    zeroed = all(float(p.grad.abs().max()) == 0.0 for p in params)
+    if rank == 0:
+        q.put((ok, views, zeroed, len(gb.buckets)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_buckets_all_reduce_mean():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    ok, views, zeroed, nb = q.get(timeout=120)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok and views and zeroed and nb >= 2
