@@ -191,27 +191,23 @@ def record_spynet_level_input(tape: Tape, supp: FM, flow_lo, flow_up: FM, cat8: 
 
 
 def record_dcn_fused(tape: Tape, x: FM, om: FM, pc, out: FM, groups, act, slope):
-    """DCNv2 backward through the fp32 planar operator (`_ext.dcn_v2_backward`, src/cuda/dcn_v2_cuda.cu:97-216): the fused
-    forward keeps no column buffer, so the operands are converted once here."""
+    """DCNv2 backward (src/cuda/dcn_v2_cuda.cu:97-216 restructured for channel-innermost fp16): the sampled columns are
+    rebuilt once (the fused forward keeps none); dW is a 1x1 weight-gradient over them, d(columns) a 1x1 conv of dY,
+    and one kernel turns d(columns) into the offset / mask gradients and the scatter to the sampled features."""
     weight, bias = pc.param_w, pc.param_b
 
     def bwd():
-        from .dcn_ext import dcn_v2_backward
         g = tape.grad(out)
         if act in (ops.ACT_RELU, ops.ACT_LRELU):
             g = ops.act_backward(g, out, act, slope)
-        G = groups
-        mask = ops.sigmoid_f32(om.ch(18 * G, 9 * G).to_nchw())
-        gi, goff, gmask, gw, gb = dcn_v2_backward(x.to_nchw(), weight.detach(), bias.detach(), om.ch(0, 18 * G).to_nchw(), mask,
-                                                  g.to_nchw(), 3, 3, 1, 1, 1, 1, 1, 1, G)
-        ops.sigmoid_backward_f32(gmask, mask)
+        cpc = ops.dcn_column_conv(pc, groups)
+        col = ops.dcn_columns(x, om, groups)
+        ops.conv_wgrad(cpc, g, col, param_grad(weight).view(-1), scale=tape.inv_scale)
+        ops.conv_bgrad(cpc, g, param_grad(bias), scale=tape.inv_scale)
+        dcol = ops.conv_dgrad(cpc, g, col, accumulate=False)            # overwrites the column buffer
+        dx32 = ops.dcn_col2im(x, om, dcol, groups, tape.grad(om))
         if tape.needs_grad(x):
-            accumulate(tape.grad(x), ops.from_nchw(gi))
-        dom = tape.grad(om)
-        accumulate(dom.ch(0, 18 * G), ops.from_nchw(goff))
-        accumulate(dom.ch(18 * G, 9 * G), ops.from_nchw(gmask))
-        ops.axpy_f32(param_grad(weight), gw, tape.inv_scale)
-        ops.axpy_f32(param_grad(bias), gb, tape.inv_scale)
+            accumulate(tape.grad(x), dx32)
 
     tape.add(bwd)
 

@@ -734,7 +734,9 @@ extern "C" int64_t tdvc_bias_grad_work_floats(int N, int C_) { return (int64_t)N
 
 extern "C" int tdvc_bias_grad(const tdvc_fmap* g, int nvalid, const int32_t* dst_index, float scale, float* db, float* work, int64_t work_floats, void* stream) {
   TDVC_CHECK(g && db && work && fmap_any(*g) && (g->C % 8) == 0 && nvalid >= 1 && nvalid <= g->C, "tdvc_bias_grad: bad arguments");
-  const int nblocks = 64;
+  // pixel ranges per image: enough workgroups to stream the map, few enough rows for the serial second stage
+  const long npix = (long)g->H * g->W;
+  const int nblocks = (int)(npix / 4096 < 1 ? 1 : (npix / 4096 > 64 ? 64 : npix / 4096));
   TDVC_CHECK(work_floats >= tdvc_bias_grad_work_floats(g->N, g->C), "tdvc_bias_grad: workspace too small");
   hipLaunchKernelGGL(channel_sum_wide_kernel, dim3(nblocks, g->N, (g->C + 255) / 256), dim3(256), 0, ST(stream), to_dev(*g), work, nblocks);
   hipLaunchKernelGGL(reduce_rows_kernel, dim3((nvalid + 255) / 256), dim3(256), 0, ST(stream), work, g->N * nblocks, g->C, nvalid, dst_index, scale, db);
@@ -764,7 +766,8 @@ extern "C" int tdvc_gate_backward(const tdvc_fmap* g, const tdvc_fmap* a, const 
              "tdvc_gate_backward: bad arguments");
   if (da) TDVC_CHECK(fmap_any(*da) && same_geom(*g, *da) && da->C == g->C, "tdvc_gate_backward: bad da");
   TDVC_CHECK(work_floats >= tdvc_gate_backward_work_floats(g->N, g->C), "tdvc_gate_backward: workspace too small");
-  const int nblocks = 64;
+  const long npix = (long)g->H * g->W;
+  const int nblocks = (int)(npix / 4096 < 1 ? 1 : (npix / 4096 > 64 ? 64 : npix / 4096));
   hipLaunchKernelGGL(gate_backward_kernel, dim3(nblocks, g->N), dim3(256), 0, ST(stream), to_dev(*g), to_dev(*a), gate, da ? to_dev(*da) : null_fmap(), work, nblocks);
   hipLaunchKernelGGL(reduce_groups_kernel, dim3((g->N * g->C + 255) / 256), dim3(256), 0, ST(stream), work, g->N, nblocks, g->C, dgate);
   return tdvc_launch_status("tdvc_gate_backward");

@@ -150,6 +150,107 @@ __global__ __launch_bounds__(256) void bgrad_kernel(const float* __restrict__ gy
   if (tid == 0) gb[co] += red[0];
 }
 
+// ---------------------------------------------------------------------------------------------------
+// fp16 channel-innermost backward of the fused DCN (training path).  Column channel order k = t * 8G + g * 8 + j
+// (tap-major, 8 channels per deformable group), the order the fused forward stages its samples in.
+//   dcn_columns_kernel : col[p][k] = mask(g,t,p) * bilinear(x[.., g*8+j], p + tap t + offset(g,t,p))      (for dW)
+//   dcn_col2im_kernel  : from dcol[p][k] = sum_co W[co][k] dY[p][co]:  d offset, d mask (raw, through the sigmoid) into
+//                        dom, and the bilinear scatter of dcol * mask into dx32 (float atomics: summation order is not
+//                        reproducible, like the reference's col2im, dcn_v2_im2col_cuda.cu:197-254)
+// One thread per (pixel, group, tap), 8 channels = one 16-byte access per bilinear corner.
+struct DcnBw {
+  FMap x, om, col;           // col doubles as dcol
+  FMap dom;
+  float* dx32;
+  int G;
+};
+
+__device__ __forceinline__ void dcn_geom(const DcnBw& p, long i, int& n, long& pix, int& g, int& t, float& h_im, float& w_im, float& mask) {
+  const long npix = (long)p.x.H * p.x.W;
+  t = (int)(i % 9);
+  long q = i / 9;
+  g = (int)(q % p.G);
+  q /= p.G;
+  pix = q % npix;
+  n = (int)(q / npix);
+  const int y = (int)(pix / p.x.W), xx = (int)(pix % p.x.W);
+  const half_t* omp = reinterpret_cast<const half_t*>(p.om.p) + (long)n * p.om.sn + pix * p.om.sp;
+  const float oh = (float)omp[g * 18 + 2 * t], ow = (float)omp[g * 18 + 2 * t + 1];
+  mask = 1.f / (1.f + __expf(-(float)omp[18 * p.G + g * 9 + t]));
+  h_im = (float)(y - 1 + t / 3) + oh;
+  w_im = (float)(xx - 1 + t % 3) + ow;
+}
+
+__global__ void dcn_columns_kernel(const DcnBw p, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int n, g, t; long pix; float h_im, w_im, mask;
+  dcn_geom(p, i, n, pix, g, t, h_im, w_im, mask);
+  const int H = p.x.H, W = p.x.W;
+  half8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (half_t)0.f;
+  if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+    const int hl = (int)floorf(h_im), wl = (int)floorf(w_im), hh = hl + 1, wh = wl + 1;
+    const float lh = h_im - hl, lw = w_im - wl;
+    const half_t* xg = reinterpret_cast<const half_t*>(p.x.p) + (long)n * p.x.sn + g * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto corner = [&](int yy, int xc, float wt) {
+      if (yy < 0 || yy > H - 1 || xc < 0 || xc > W - 1) return;
+      const half8 v = *reinterpret_cast<const half8*>(xg + ((long)yy * W + xc) * p.x.sp);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += wt * (float)v[j];
+    };
+    corner(hl, wl, (1.f - lh) * (1.f - lw));
+    corner(hl, wh, (1.f - lh) * lw);
+    corner(hh, wl, lh * (1.f - lw));
+    corner(hh, wh, lh * lw);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)(acc[j] * mask);
+  }
+  *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.col.p) + (long)n * p.col.sn + pix * p.col.sp + t * 8 * p.G + g * 8) = o;
+}
+
+__global__ void dcn_col2im_kernel(const DcnBw p, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int n, g, t; long pix; float h_im, w_im, mask;
+  dcn_geom(p, i, n, pix, g, t, h_im, w_im, mask);
+  const int H = p.x.H, W = p.x.W;
+  if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) return;
+  const half8 dc8 = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(p.col.p) + (long)n * p.col.sn + pix * p.col.sp + t * 8 * p.G + g * 8);
+  float dc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dc[j] = (float)dc8[j];
+  const int hl = (int)floorf(h_im), wl = (int)floorf(w_im), hh = hl + 1, wh = wl + 1;
+  const float lh = h_im - hl, lw = w_im - wl;
+  const half_t* xg = reinterpret_cast<const half_t*>(p.x.p) + (long)n * p.x.sn + g * 8;
+  float* dxn = p.dx32 + ((long)n * H * W) * (8 * p.G) + g * 8;
+  float dval = 0.f, dh = 0.f, dw = 0.f;                       // sum_c dcol_c * {val_c, dval_c/dh, dval_c/dw}
+  auto corner = [&](int yy, int xc, float wt, float wth, float wtw) {
+    if (yy < 0 || yy > H - 1 || xc < 0 || xc > W - 1) return;
+    const long off = ((long)yy * W + xc);
+    const half8 v = *reinterpret_cast<const half8*>(xg + off * p.x.sp);
+    float* d = dxn + off * (8 * p.G);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xv = (float)v[j];
+      dval += dc[j] * wt * xv;
+      dh += dc[j] * wth * xv;
+      dw += dc[j] * wtw * xv;
+      atomicAdd(d + j, dc[j] * mask * wt);
+    }
+  };
+  corner(hl, wl, (1.f - lh) * (1.f - lw), -(1.f - lw), -(1.f - lh));
+  corner(hl, wh, (1.f - lh) * lw, -lw, (1.f - lh));
+  corner(hh, wl, lh * (1.f - lw), (1.f - lw), -lh);
+  corner(hh, wh, lh * lw, lw, lh);
+  half_t* dop = reinterpret_cast<half_t*>(p.dom.p) + (long)n * p.dom.sn + pix * p.dom.sp;
+  dop[g * 18 + 2 * t] = (half_t)((float)dop[g * 18 + 2 * t] + dh * mask);
+  dop[g * 18 + 2 * t + 1] = (half_t)((float)dop[g * 18 + 2 * t + 1] + dw * mask);
+  dop[18 * p.G + g * 9 + t] = (half_t)((float)dop[18 * p.G + g * 9 + t] + dval * mask * (1.f - mask));
+}
+
 inline dim3 g1(long n) { return dim3((unsigned)((n + 255) / 256)); }
 
 }  // namespace
@@ -195,4 +296,28 @@ extern "C" int tdvc_dcn_v2_backward_f32(const float* input, const float* weight,
     hipLaunchKernelGGL(bgrad_kernel, dim3(Cout), dim3(256), 0, st, gn, grad_bias, P);
   }
   return tdvc_launch_status("tdvc_dcn_v2_backward_f32");
+}
+
+static inline bool dcn_bw_ok(const tdvc_fmap& x, const tdvc_fmap& om, const tdvc_fmap& col, int G) {
+  return fmap_ok16(x) && fmap_ok16(om) && fmap_ok16(col) && G >= 1 && x.C == 8 * G && om.C >= 27 * G && col.C == 72 * G && x.N == om.N && x.N == col.N &&
+         x.H == om.H && x.W == om.W && x.H == col.H && x.W == col.W && (long)x.H * x.W < 2147483647L;
+}
+
+extern "C" int tdvc_dcn_columns(const tdvc_fmap* x, const tdvc_fmap* om, int groups, const tdvc_fmap* col, void* stream) {
+  TDVC_CHECK(x && om && col && dcn_bw_ok(*x, *om, *col, groups), "tdvc_dcn_columns: bad arguments (x C = 8*groups, om C >= 27*groups, col C = 72*groups)");
+  DcnBw p;
+  p.x = to_dev(*x); p.om = to_dev(*om); p.col = to_dev(*col); p.dom = null_fmap(); p.dx32 = nullptr; p.G = groups;
+  const long total = (long)x->N * x->H * x->W * groups * 9;
+  hipLaunchKernelGGL(dcn_columns_kernel, g1(total), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, total);
+  return tdvc_launch_status("tdvc_dcn_columns");
+}
+
+extern "C" int tdvc_dcn_col2im(const tdvc_fmap* x, const tdvc_fmap* om, const tdvc_fmap* dcol, int groups, float* dx32, const tdvc_fmap* dom, void* stream) {
+  TDVC_CHECK(x && om && dcol && dx32 && dom && dcn_bw_ok(*x, *om, *dcol, groups) && fmap_ok16(*dom) && dom->C >= 27 * groups && dom->N == x->N &&
+                 dom->H == x->H && dom->W == x->W, "tdvc_dcn_col2im: bad arguments");
+  DcnBw p;
+  p.x = to_dev(*x); p.om = to_dev(*om); p.col = to_dev(*dcol); p.dom = to_dev(*dom); p.dx32 = dx32; p.G = groups;
+  const long total = (long)x->N * x->H * x->W * groups * 9;
+  hipLaunchKernelGGL(dcn_col2im_kernel, g1(total), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, total);
+  return tdvc_launch_status("tdvc_dcn_col2im");
 }

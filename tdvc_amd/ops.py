@@ -151,6 +151,9 @@ class PackedConv:
             self.bias[:self.cout] = b[torch.from_numpy(convpack.shuffle_perm(self.cout)).to(b.device)] if self.shuffle else b
         if self.dgrad is not None:
             self.dgrad.repack()
+        aux = self.__dict__.get("_colpc")          # the DCN weight seen as a 1x1 conv over sampled columns (backward only)
+        if aux is not None:
+            aux.repack()
 
 
 def _cout_pad(cout):
@@ -462,6 +465,33 @@ def dcn_fused(x: FM, om: FM, pc: PackedConv, out: FM, groups=8, act=ACT_NONE, sl
     L.check(L.lib().tdvc_dcn_fused(C.byref(d), _stream()), "dcn_fused")
     _rec("dcn_fused", x, om, pc, out, groups, act, slope)
     return out
+
+
+def dcn_columns(x: FM, om: FM, groups: int) -> FM:
+    col = FM.empty(x.N, x.H, x.W, 72 * groups, device=x.t.device)
+    d1, d2, d3 = x.desc(), om.desc(), col.desc()
+    L.check(L.lib().tdvc_dcn_columns(C.byref(d1), C.byref(d2), groups, C.byref(d3), _stream()), "dcn_columns")
+    return col
+
+
+def dcn_col2im(x: FM, om: FM, dcol: FM, groups: int, dom: FM) -> FM:
+    """-> dx as an fp32 FM (fresh, float-atomic scatter); offset / mask gradients accumulate into `dom`"""
+    dx32 = FM.zeros(x.N, x.H, x.W, x.C, dtype=torch.float32, device=x.t.device)
+    d1, d2, d3, d4 = x.desc(), om.desc(), dcol.desc(), dom.desc()
+    L.check(L.lib().tdvc_dcn_col2im(C.byref(d1), C.byref(d2), C.byref(d3), groups, dx32.t.data_ptr(), C.byref(d4), _stream()), "dcn_col2im")
+    return dx32
+
+
+def dcn_column_conv(pc: PackedConv, groups: int) -> PackedConv:
+    """the DCN weight (cout, 8G, 3, 3) as a 1x1 conv over the 72G column channels k = t*8G + c (weight offset c*9 + t)"""
+    cp = pc.__dict__.get("_colpc")
+    if cp is None:
+        cin = 8 * groups
+        chan = np.array([c * 9 + t for t in range(9) for c in range(cin)], dtype=np.int64)
+        lay = convpack.WeightLayout(pc.cout, 9 * cin, 1, 1, np.arange(pc.cout, dtype=np.int64) * cin * 9, chan, np.zeros(1, dtype=np.int64))
+        cp = pack_conv(pc.wsrc, None, stride=1, pad=0, layout=lay, param_w=pc.param_w)
+        pc.__dict__["_colpc"] = cp
+    return cp
 
 
 def sigmoid_f32(x: torch.Tensor) -> torch.Tensor:
