@@ -84,14 +84,20 @@ __global__ __launch_bounds__(256) void channel_sum_wide_kernel(FMap x, float* pa
   }
 }
 
-// out[dst[c] or c] += scale * sum_rows partial[row][c]  (rows summed in order)
-__global__ void reduce_rows_kernel(const float* partial, int rows, int C_, int nvalid, const int* dst, float scale, float* out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= nvalid) return;
+// out[dst[c] or c] += scale * sum_rows partial[row][c]: 64 channels x 4 row lanes per workgroup, fixed order
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* partial, int rows, int C_, int nvalid, const int* dst, float scale, float* out) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += partial[(long)r * C_ + c];
-  const int d = dst ? dst[c] : c;
-  if (d >= 0) out[d] += s * scale;
+  if (c < nvalid)
+    for (int r = rl; r < rows; r += 4) s += partial[(long)r * C_ + c];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < nvalid) {
+    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    const int d = dst ? dst[c] : c;
+    if (d >= 0) out[d] += t * scale;
+  }
 }
 
 // dst[..., c] = c < src.C ? src[..., c] : 0 (any dtypes; dst.C % 8 == 0 when fp16)
@@ -736,10 +742,10 @@ extern "C" int tdvc_bias_grad(const tdvc_fmap* g, int nvalid, const int32_t* dst
   TDVC_CHECK(g && db && work && fmap_any(*g) && (g->C % 8) == 0 && nvalid >= 1 && nvalid <= g->C, "tdvc_bias_grad: bad arguments");
   // pixel ranges per image: enough workgroups to stream the map, few enough rows for the serial second stage
   const long npix = (long)g->H * g->W;
-  const int nblocks = (int)(npix / 4096 < 1 ? 1 : (npix / 4096 > 64 ? 64 : npix / 4096));
+  const int nblocks = (int)(npix / 1024 < 1 ? 1 : (npix / 1024 > 64 ? 64 : npix / 1024));
   TDVC_CHECK(work_floats >= tdvc_bias_grad_work_floats(g->N, g->C), "tdvc_bias_grad: workspace too small");
   hipLaunchKernelGGL(channel_sum_wide_kernel, dim3(nblocks, g->N, (g->C + 255) / 256), dim3(256), 0, ST(stream), to_dev(*g), work, nblocks);
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((nvalid + 255) / 256), dim3(256), 0, ST(stream), work, g->N * nblocks, g->C, nvalid, dst_index, scale, db);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((nvalid + 63) / 64), dim3(256), 0, ST(stream), work, g->N * nblocks, g->C, nvalid, dst_index, scale, db);
   return tdvc_launch_status("tdvc_bias_grad");
 }
 

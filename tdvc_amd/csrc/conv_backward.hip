@@ -220,10 +220,10 @@ extern "C" int tdvc_pack_conv_weights_indexed(const float* w, const int32_t* row
 }
 
 static int wgrad_workers(int co_tiles, int ci_tiles, int groups, int nblocks) {
-  int w = 1024 / (co_tiles * ci_tiles * groups);
+  int w = 1024 / (co_tiles * ci_tiles * groups);      // ~4 workgroups per CU over the whole launch
   if (w < 1) w = 1;
   if (w > nblocks) w = nblocks;
-  if (w > 64) w = 64;
+  if (w > 256) w = 256;                               // bounds the partial-sum workspace (workers x |dW| floats)
   return w;
 }
 

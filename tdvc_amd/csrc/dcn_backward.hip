@@ -238,7 +238,7 @@ __global__ void dcn_col2im_kernel(const DcnBw p, long total) {
       dval += dc[j] * wt * xv;
       dh += dc[j] * wth * xv;
       dw += dc[j] * wtw * xv;
-      atomicAdd(d + j, dc[j] * mask * wt);
+      unsafeAtomicAdd(d + j, dc[j] * mask * wt);          // hardware global_atomic_add_f32 (plain atomicAdd is a CAS loop)
     }
   };
   corner(hl, wl, (1.f - lh) * (1.f - lw), -(1.f - lw), -(1.f - lh));
