@@ -211,44 +211,77 @@ __global__ void dcn_columns_kernel(const DcnBw p, long total) {
   *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.col.p) + (long)n * p.col.sn + pix * p.col.sp + t * 8 * p.G + g * 8) = o;
 }
 
-__global__ void dcn_col2im_kernel(const DcnBw p, long total) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  int n, g, t; long pix; float h_im, w_im, mask;
-  dcn_geom(p, i, n, pix, g, t, h_im, w_im, mask);
+// One workgroup = a 16x16 pixel tile of one (image, deformable group); the scatter goes to an LDS window of 32x32
+// pixels x 8 channels around the tile (ds_add_f32), samples that land outside it (offsets beyond +-8 pixels) go
+// straight to global memory; the window is then flushed with one global float atomic per non-zero element: ~9x
+// fewer global atomics than one per corner, and almost uncontended.
+constexpr int C2I_T = 16, C2I_R = 8, C2I_W = C2I_T + 2 * C2I_R;
+__global__ __launch_bounds__(256) void dcn_col2im_kernel(const DcnBw p) {
+  __shared__ float win[C2I_W * C2I_W * 8];
   const int H = p.x.H, W = p.x.W;
-  if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) return;
-  const half8 dc8 = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(p.col.p) + (long)n * p.col.sn + pix * p.col.sp + t * 8 * p.G + g * 8);
-  float dc[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) dc[j] = (float)dc8[j];
-  const int hl = (int)floorf(h_im), wl = (int)floorf(w_im), hh = hl + 1, wh = wl + 1;
-  const float lh = h_im - hl, lw = w_im - wl;
+  const int tiles_x = (W + C2I_T - 1) / C2I_T;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int g = blockIdx.y % p.G, n = blockIdx.y / p.G;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < C2I_W * C2I_W * 8; i += 256) win[i] = 0.f;
+  __syncthreads();
+  const int y = ty * C2I_T + (tid >> 4), xx = tx * C2I_T + (tid & 15);
+  const int wy0 = ty * C2I_T - C2I_R, wx0 = tx * C2I_T - C2I_R;
   const half_t* xg = reinterpret_cast<const half_t*>(p.x.p) + (long)n * p.x.sn + g * 8;
   float* dxn = p.dx32 + ((long)n * H * W) * (8 * p.G) + g * 8;
-  float dval = 0.f, dh = 0.f, dw = 0.f;                       // sum_c dcol_c * {val_c, dval_c/dh, dval_c/dw}
-  auto corner = [&](int yy, int xc, float wt, float wth, float wtw) {
-    if (yy < 0 || yy > H - 1 || xc < 0 || xc > W - 1) return;
-    const long off = ((long)yy * W + xc);
-    const half8 v = *reinterpret_cast<const half8*>(xg + off * p.x.sp);
-    float* d = dxn + off * (8 * p.G);
+  if (y < H && xx < W) {
+    const long pix = (long)y * W + xx;
+    const half_t* omp = reinterpret_cast<const half_t*>(p.om.p) + (long)n * p.om.sn + pix * p.om.sp;
+    half_t* dop = reinterpret_cast<half_t*>(p.dom.p) + (long)n * p.dom.sn + pix * p.dom.sp;
+    const half_t* dcp = reinterpret_cast<const half_t*>(p.col.p) + (long)n * p.col.sn + pix * p.col.sp + g * 8;
+    for (int t = 0; t < 9; ++t) {
+      const float oh = (float)omp[g * 18 + 2 * t], ow = (float)omp[g * 18 + 2 * t + 1];
+      const float mask = 1.f / (1.f + __expf(-(float)omp[18 * p.G + g * 9 + t]));
+      const float h_im = (float)(y - 1 + t / 3) + oh, w_im = (float)(xx - 1 + t % 3) + ow;
+      if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) continue;
+      const half8 dc8 = *reinterpret_cast<const half8*>(dcp + t * 8 * p.G);
+      float dc[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float xv = (float)v[j];
-      dval += dc[j] * wt * xv;
-      dh += dc[j] * wth * xv;
-      dw += dc[j] * wtw * xv;
-      unsafeAtomicAdd(d + j, dc[j] * mask * wt);          // hardware global_atomic_add_f32 (plain atomicAdd is a CAS loop)
+      for (int j = 0; j < 8; ++j) dc[j] = (float)dc8[j];
+      const int hl = (int)floorf(h_im), wl = (int)floorf(w_im), hh = hl + 1, wh = wl + 1;
+      const float lh = h_im - hl, lw = w_im - wl;
+      float dval = 0.f, dh = 0.f, dw = 0.f;                   // sum_c dcol_c * {val_c, dval_c/dh, dval_c/dw}
+      auto corner = [&](int yy, int xc, float wt, float wth, float wtw) {
+        if (yy < 0 || yy > H - 1 || xc < 0 || xc > W - 1) return;
+        const long off = ((long)yy * W + xc);
+        const half8 v = *reinterpret_cast<const half8*>(xg + off * p.x.sp);
+        const int ly = yy - wy0, lx = xc - wx0;
+        const bool inwin = ly >= 0 && ly < C2I_W && lx >= 0 && lx < C2I_W;
+        float* dl = win + (ly * C2I_W + lx) * 8;
+        float* dg = dxn + off * (8 * p.G);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xv = (float)v[j];
+          dval += dc[j] * wt * xv;
+          dh += dc[j] * wth * xv;
+          dw += dc[j] * wtw * xv;
+          const float a = dc[j] * mask * wt;
+          if (inwin) atomicAdd(dl + j, a);
+          else unsafeAtomicAdd(dg + j, a);
+        }
+      };
+      corner(hl, wl, (1.f - lh) * (1.f - lw), -(1.f - lw), -(1.f - lh));
+      corner(hl, wh, (1.f - lh) * lw, -lw, (1.f - lh));
+      corner(hh, wl, lh * (1.f - lw), (1.f - lw), -lh);
+      corner(hh, wh, lh * lw, lw, lh);
+      dop[g * 18 + 2 * t] = (half_t)((float)dop[g * 18 + 2 * t] + dh * mask);
+      dop[g * 18 + 2 * t + 1] = (half_t)((float)dop[g * 18 + 2 * t + 1] + dw * mask);
+      dop[18 * p.G + g * 9 + t] = (half_t)((float)dop[18 * p.G + g * 9 + t] + dval * mask * (1.f - mask));
     }
-  };
-  corner(hl, wl, (1.f - lh) * (1.f - lw), -(1.f - lw), -(1.f - lh));
-  corner(hl, wh, (1.f - lh) * lw, -lw, (1.f - lh));
-  corner(hh, wl, lh * (1.f - lw), (1.f - lw), -lh);
-  corner(hh, wh, lh * lw, lw, lh);
-  half_t* dop = reinterpret_cast<half_t*>(p.dom.p) + (long)n * p.dom.sn + pix * p.dom.sp;
-  dop[g * 18 + 2 * t] = (half_t)((float)dop[g * 18 + 2 * t] + dh * mask);
-  dop[g * 18 + 2 * t + 1] = (half_t)((float)dop[g * 18 + 2 * t + 1] + dw * mask);
-  dop[18 * p.G + g * 9 + t] = (half_t)((float)dop[18 * p.G + g * 9 + t] + dval * mask * (1.f - mask));
+  }
+  __syncthreads();
+  for (int i = tid; i < C2I_W * C2I_W * 8; i += 256) {
+    const float v = win[i];
+    if (v == 0.f) continue;
+    const int j = i & 7, q = i >> 3;
+    const int yy = wy0 + q / C2I_W, xc = wx0 + q % C2I_W;
+    if (yy >= 0 && yy < H && xc >= 0 && xc < W) unsafeAtomicAdd(dxn + ((long)yy * W + xc) * (8 * p.G) + j, v);
+  }
 }
 
 inline dim3 g1(long n) { return dim3((unsigned)((n + 255) / 256)); }
@@ -317,7 +350,7 @@ extern "C" int tdvc_dcn_col2im(const tdvc_fmap* x, const tdvc_fmap* om, const td
                  dom->H == x->H && dom->W == x->W, "tdvc_dcn_col2im: bad arguments");
   DcnBw p;
   p.x = to_dev(*x); p.om = to_dev(*om); p.col = to_dev(*dcol); p.dom = to_dev(*dom); p.dx32 = dx32; p.G = groups;
-  const long total = (long)x->N * x->H * x->W * groups * 9;
-  hipLaunchKernelGGL(dcn_col2im_kernel, g1(total), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, total);
+  const dim3 grid((unsigned)(((x->W + C2I_T - 1) / C2I_T) * ((x->H + C2I_T - 1) / C2I_T)), (unsigned)(x->N * groups));
+  hipLaunchKernelGGL(dcn_col2im_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
   return tdvc_launch_status("tdvc_dcn_col2im");
 }
