@@ -191,3 +191,12 @@ def test_pad_crop_match_oracle():
     assert torch.equal(crop(p, (1080, 1920)), x) and torch.equal(crop(p, (1080, 1920)), crop_to(p, (1080, 1920)))
     y = torch.randn(1, 3, 59, 67)
     assert torch.equal(pad(y, 64), pad_to(y, 64)) and torch.equal(crop(pad(y, 64), (59, 67)), y)
+
+
+def test_training_sampler_matches_reference_rule():
+    """dataset.py:211-247: input im{t}, references [im1, t-3 .. t-1] padded by repeating the last, plus im7 <- [1,1,3,5]"""
+    from tdvc_amd.tools.train import septuplet_samples
+    frames = torch.arange(7).float().view(7, 1, 1, 1).expand(7, 3, 2, 2).contiguous() + 1.0      # frame value = 1-based index
+    got = [(int(x[0, 0, 0]), [int(r[0, 0, 0]) for r in refs]) for x, refs in septuplet_samples(frames)]
+    assert got == [(2, [1, 1, 1, 1]), (3, [1, 1, 2, 2]), (4, [1, 1, 2, 3]), (5, [1, 2, 3, 4]), (6, [1, 3, 4, 5]), (7, [1, 4, 5, 6]),
+                   (7, [1, 1, 3, 5])]
