@@ -7,7 +7,8 @@
     aux_loss.backward(); aux_optimizer.step()                        (train.py:142-152)
 
 The forward and backward run in the HIP kernels (forward under `autograd.record`, backward = the tape); the loss
-scale is a constant (the weight-gradient kernels un-scale, so there is no separate `unscale_` pass), gradient
+scale follows GradScaler's skip / halve / grow policy (the weight-gradient kernels un-scale, so there is no separate
+`unscale_` pass), gradient
 clipping and Adam are torch's device-side optimizer utilities, the auxiliary (quantile) loss is parameter-space
 autograd.  With several ranks the parameter gradients are averaged by RCCL before clipping, so every rank clips
 and steps identically; `GradBuckets` packs them into a few flat buffers.
@@ -73,11 +74,15 @@ class GradBuckets:
 
 
 class TrainStep:
-    def __init__(self, model, train_lambda: float = 2048.0, lr: float = 1e-4, loss_scale: float = 1024.0, clip: float = 2.0):
+    def __init__(self, model, train_lambda: float = 2048.0, lr: float = 1e-4, loss_scale: float = 1024.0, clip: float = 2.0,
+                 dynamic_scale: bool = True, growth_interval: int = 2000):
         self.model = model
         self.lam = float(train_lambda)
         self.loss_scale = float(loss_scale)
         self.clip = float(clip)
+        # torch.cuda.amp.GradScaler's policy (train.py:101,146-149): skip the step and halve the scale when a gradient is
+        # not finite, double it after `growth_interval` clean steps
+        self.dynamic_scale, self.growth_interval, self._clean_steps = bool(dynamic_scale), int(growth_interval), 0
         main, aux = split_optim_params(model)
         named = dict(model.named_parameters())
         self.main_params = [named[n] for n in main]
@@ -102,11 +107,22 @@ class TrainStep:
             tape.rate_grad = 1.0 / float(B * H * W)
             tape.backward()
         self.buckets.all_reduce_mean()
-        gnorm = torch.nn.utils.clip_grad_norm_(self.main_params, self.clip)
-        self.optimizer.step()
+        finite = all(bool(torch.isfinite(b).all()) for b in self.buckets.buckets)      # after the mean: every rank agrees
+        if finite:
+            gnorm = torch.nn.utils.clip_grad_norm_(self.main_params, self.clip)
+            self.optimizer.step()
+            self._clean_steps += 1
+            if self.dynamic_scale and self._clean_steps % self.growth_interval == 0:
+                self.loss_scale *= 2.0
+        else:
+            gnorm = torch.tensor(float("nan"))
+            if self.dynamic_scale:
+                self.loss_scale *= 0.5
+                self._clean_steps = 0
         aux = aux_mv + aux_res
         aux.backward()
         self.aux_optimizer.step()
         refresh_packed(model)
         return dict(rd_loss=float(self.lam * mse + bpp_res.mean() + bpp_mv.mean()), mse=float(mse), bpp_res=float(bpp_res.mean()),
-                    bpp_mv=float(bpp_mv.mean()), aux_loss=float(aux.detach()), grad_norm=float(gnorm))
+                    bpp_mv=float(bpp_mv.mean()), aux_loss=float(aux.detach()), grad_norm=float(gnorm), loss_scale=self.loss_scale,
+                    skipped=not finite)
