@@ -79,6 +79,8 @@ __device__ __forceinline__ half4 tr_read(const unsigned char* p) {
   return __builtin_bit_cast(half4, v);
 }
 
+// XL = 16-byte X-tile pieces per thread (tile pixels x 4 / 256, rounded up): 6 for 3x3 stride 1, 9 for 7x7, 18 for stride 2
+template <int XL>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* gt = smem;                                         // dY tile: WG_TH*WG_TW pixels x PSG
@@ -102,39 +104,61 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   const int khalf = gq >> 1;                                        // k = 8*khalf + {0..7}
   const int colbase = 16 * (gq & 1) + 4 * cp;                       // column (channel) this lane ADDRESSES
 
-  for (int blk = worker; blk < p.nblocks; blk += nworkers) {
+  // Tiles travel global -> registers -> LDS; the NEXT block's loads are issued before this block's contraction and
+  // land under it (the first version loaded synchronously and spent most of a block waiting on HBM latency).
+  constexpr int GL = WG_TH * WG_TW * (WG_CO / 8) / 256;             // 8 dY pieces per thread
+  half8 gr[GL], xr[XL];
+  const int x_items = p.tih * p.tiw * (WG_CI / 8);
+  auto prefetch = [&](int blk) {
     const int n = blk / (p.blocks_x * p.blocks_y);
     const int rem = blk - n * (p.blocks_x * p.blocks_y);
     const int by = rem / p.blocks_x, bx = rem - by * p.blocks_x;
     const int oy0 = by * WG_TH, ox0 = bx * WG_TW;
     const int iy0 = oy0 * p.stride - p.pad, ix0 = ox0 * p.stride - p.pad;
-    __syncthreads();                                                // previous block's reads are done
-    // ---- stage dY tile (zero outside the output / beyond the channel count)
-    for (int it = tid; it < WG_TH * WG_TW * (WG_CO / 8); it += 256) {
+#pragma unroll
+    for (int j = 0; j < GL; ++j) {
+      const int it = tid + j * 256;
       const int c8 = it & 7, px = it >> 3;
       const int yy = px / WG_TW, xx = px - yy * WG_TW;
       const int oy = oy0 + yy, ox = ox0 + xx, c = co0 + c8 * 8;
       half8 v;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
+      for (int q = 0; q < 8; ++q) v[q] = (half_t)0.f;
       if (oy < p.Ho && ox < p.Wo && c < p.g.C)
         v = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(p.g.p) + (long)n * p.g.sn + ((long)oy * p.Wo + ox) * p.g.sp + c);
-      *reinterpret_cast<half8*>(gt + px * PSG + c8 * 16) = v;
+      gr[j] = v;
     }
-    // ---- stage X tile
-    for (int it = tid; it < p.tih * p.tiw * (WG_CI / 8); it += 256) {
+#pragma unroll
+    for (int j = 0; j < XL; ++j) {
+      const int it = tid + j * 256;
       const int c8 = it & 3, px = it >> 2;
       const int yy = px / p.tiw, xx = px - yy * p.tiw;
       const int iy = iy0 + yy, ix = ix0 + xx, c = ci0 + c8 * 8;
       half8 v;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
-      if (iy >= 0 && iy < p.x.H && ix >= 0 && ix < p.x.W && c < p.x.C)
+      for (int q = 0; q < 8; ++q) v[q] = (half_t)0.f;
+      if (it < x_items && iy >= 0 && iy < p.x.H && ix >= 0 && ix < p.x.W && c < p.x.C)
         v = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(p.x.p) + (long)n * p.x.sn + ((long)iy * p.x.W + ix) * p.x.sp + c);
       if (p.square_x) v = v * v;
-      *reinterpret_cast<half8*>(xt + px * PSX + c8 * 16) = v;
+      xr[j] = v;
+    }
+  };
+
+  if (worker < p.nblocks) prefetch(worker);
+  for (int blk = worker; blk < p.nblocks; blk += nworkers) {
+    __syncthreads();                                                // previous block's reads are done
+#pragma unroll
+    for (int j = 0; j < GL; ++j) {
+      const int it = tid + j * 256;
+      *reinterpret_cast<half8*>(gt + (it >> 3) * PSG + (it & 7) * 16) = gr[j];
+    }
+#pragma unroll
+    for (int j = 0; j < XL; ++j) {
+      const int it = tid + j * 256;
+      if (it < x_items) *reinterpret_cast<half8*>(xt + (it >> 2) * PSX + (it & 3) * 16) = xr[j];
     }
     __syncthreads();
+    if (blk + nworkers < p.nblocks) prefetch(blk + nworkers);
     // ---- contraction: k-steps of 16 consecutive output pixels of one row
     for (int yy = 0; yy < WG_TH; ++yy) {
 #pragma unroll
@@ -264,18 +288,21 @@ extern "C" int tdvc_conv_wgrad(const tdvc_fmap* g, const tdvc_fmap* x, int cout,
   p.square_x = square_x;
   const int groups = (ntaps + WG_MAXT - 1) / WG_MAXT;
   const int workers = wgrad_workers(p.co_tiles, p.ci_tiles, groups, p.nblocks);
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (err != hipSuccess) { tdvc_set_error("tdvc_conv_wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(err)); return (int)err; }
-    attr_done = true;
-  }
+  const int xl = (p.tih * p.tiw * (WG_CI / 8) + 255) / 256;
+  TDVC_CHECK(xl <= 18, "tdvc_conv_wgrad: X tile of %dx%d pixels needs %d pieces per thread (max 18)", p.tih, p.tiw, xl);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  for (int gI = 0; gI < groups; ++gI) {
-    p.tap0 = gI * WG_MAXT;
-    p.ntaps = ntaps - p.tap0 < WG_MAXT ? ntaps - p.tap0 : WG_MAXT;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.co_tiles * p.ci_tiles, workers), dim3(256), lds, st, p);
-  }
+  auto go = [&](auto kern) -> int {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (err != hipSuccess) { tdvc_set_error("tdvc_conv_wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(err)); return (int)err; }
+    for (int gI = 0; gI < groups; ++gI) {
+      p.tap0 = gI * WG_MAXT;
+      p.ntaps = ntaps - p.tap0 < WG_MAXT ? ntaps - p.tap0 : WG_MAXT;
+      hipLaunchKernelGGL(kern, dim3(p.co_tiles * p.ci_tiles, workers), dim3(256), lds, st, p);
+    }
+    return 0;
+  };
+  const int rc = xl <= 6 ? go(&conv_wgrad_kernel<6>) : (xl <= 9 ? go(&conv_wgrad_kernel<9>) : go(&conv_wgrad_kernel<18>));
+  if (rc) return rc;
   const long total = (long)cout * cin * ntaps;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, work, workers, p.co_tiles * WG_CO,
                      p.ci_tiles * WG_CI, ntaps, row_off, chan_off, tap_off, cout, cin, scale, dw);
