@@ -484,7 +484,7 @@ class Cheng2020Anchor(nn.Module, PackCache):
         return {"strings": [y_strings, z_strings], "shape": (z.H, z.W), "_debug": dbg}
 
     @torch.no_grad()
-    def decompress(self, strings, shape):
+    def decompress(self, strings, shape, synth=True):
         """strings as returned by compress(); serial raster-order context decoding (the stream order of
         compressai's bitstream).  -> {"x_hat": FM, "y_hat": FM}"""
         dev = self.context_prediction.weight.device
@@ -517,7 +517,7 @@ class Cheng2020Anchor(nn.Module, PackCache):
                     sym[h, w] = torch.from_numpy(q).to(dev)
                     ops.ar_quantize(None, gp, pos, 1, table, y_hat, sym, idx, symbols_in=sym)
             dec.close()
-        return {"x_hat": self.run_g_s(y_hat_all), "y_hat": y_hat_all}
+        return {"x_hat": self.run_g_s(y_hat_all) if synth else None, "y_hat": y_hat_all}
 
 
 def _g_a(N):

@@ -108,3 +108,65 @@ class VideoCompressor(nn.Module):
         if training:
             return recon, bpp_res, bpp_mv, self.mvCoder.aux_loss(), self.resCoder.aux_loss()
         return recon, bpp_res, bpp_mv
+
+    # ---- real encode / decode (the reference only sketches it: tools/utils/encoder.py, decoder.py) ----
+    def _prepare(self, refer_frames, input_image=None):
+        B, _, _, H, W = refer_frames.shape
+        if H % 64 or W % 64:
+            raise RuntimeError(f"frames must be padded to a multiple of 64 (got {H}x{W})")
+        dev = refer_frames.device
+        refs8 = ops.from_nchw(refer_frames.float().reshape(B * 4, 3, H, W), Cpad=8)
+        last = refer_frames[:, 3].float()
+        ref8 = ops.from_nchw(last, Cpad=8)
+        iframe8 = ops.from_nchw(refer_frames[:, 0].float(), Cpad=8)
+        feats = FM.empty(B, H, W, 192, device=dev)
+        self.extra_fea.run(ref8, feats.ch(64, 64))
+        return B, H, W, dev, refs8, last, iframe8, feats
+
+    def _reconstruct(self, mv_y_hat: FM, res_y_hat_fn, feats: FM, refs8: FM, iframe8: FM):
+        """decoder-side reconstruction from the decoded motion latents; `res_y_hat_fn(pred)` supplies the residual latents
+        (the encoder codes them against this very prediction, the decoder reads them from the stream)"""
+        B, H, W, dev = feats.N, feats.H, feats.W, feats.t.device
+        mv_hat = self.mvCoder.run_g_s(mv_y_hat)
+        xt = FM.empty(B, H, W, 256, device=dev)
+        self.mcnet.run(mv_hat, feats, xt.ch(192, 64))
+        pred = FM.empty(B, H, W, 64, device=dev)
+        self.mcfilter.run(xt, refs8, pred)
+        recon_f = self.resCoder.run_g_s(res_y_hat_fn(pred), res=pred)
+        return self.loopfilter.run(recon_f, iframe8, training=False)
+
+    @torch.no_grad()
+    def encode(self, input_image, refer_frames):
+        """-> {"strings": [mv_y, mv_z, res_y, res_z] (lists over the batch), "shapes": z shapes, "recon": (B,3,H,W)}.
+        The reconstruction is the DECODER's: it is built from the coded symbols, so a closed-loop encoder and the decoder
+        stay bit-identical."""
+        assert not self.training
+        B, H, W, dev, refs8, last, iframe8, feats = self._prepare(refer_frames)
+        x = input_image.float()
+        f_cur = self.extra_fea.run(ops.from_nchw(x, Cpad=8), feats.ch(0, 64))
+        estmv = self.motion_est.run(feats, ops.from_nchw(x, Cpad=4, dtype=torch.float32), ops.from_nchw(last, Cpad=4, dtype=torch.float32))
+        self.mvCoder.update()
+        self.resCoder.update()
+        mv = self.mvCoder.compress(estmv)
+        cat = lambda dbg: FM(torch.cat([d["y_hat"].t for d in dbg], 0))
+        out = {}
+
+        def res_y_hat(pred):
+            resid = ops.scale_act_res(f_cur, FM.empty(B, H, W, 64, device=dev), res=pred, res_sign=-1.0)
+            out["res"] = self.resCoder.compress(resid)
+            return cat(out["res"]["_debug"])
+        recon = self._reconstruct(cat(mv["_debug"]), res_y_hat, feats, refs8, iframe8)
+        rs = out["res"]
+        return {"strings": [mv["strings"][0], mv["strings"][1], rs["strings"][0], rs["strings"][1]],
+                "shapes": [mv["shape"], rs["shape"]], "recon": recon}
+
+    @torch.no_grad()
+    def decode(self, strings, shapes, refer_frames):
+        """inverse of encode(): strings [mv_y, mv_z, res_y, res_z] + z shapes + the reference list -> (B,3,H,W)"""
+        assert not self.training
+        B, H, W, dev, refs8, last, iframe8, feats = self._prepare(refer_frames)
+        self.mvCoder.update()
+        self.resCoder.update()
+        mv = self.mvCoder.decompress([strings[0], strings[1]], shapes[0])
+        return self._reconstruct(mv["y_hat"], lambda pred: self.resCoder.decompress([strings[2], strings[3]], shapes[1], synth=False)["y_hat"],
+                                 feats, refs8, iframe8)

@@ -8,6 +8,7 @@ checkpoint that does not ship; this driver keeps its behaviour
 given by --pretrain), one process per GPU with GOPs sharded round-robin across ranks.
 
   python -m tdvc_amd.tools.predict --gops 2 --height 1080 --width 1920
+  python -m tdvc_amd.tools.predict --gops 1 --height 128 --width 192 --bitstream-dir /tmp/tdvc_bits     # real bitstreams
   python -m torch.distributed.run --nproc-per-node 8 -m tdvc_amd.tools.predict --gops 16
 """
 from __future__ import annotations
@@ -26,13 +27,34 @@ from ..parallel import gather_frame_stats, shard_gops
 from ..synth import fill_parameters, make_gop, ref_list
 
 
-def code_gop(net, frames: torch.Tensor, enable_amp: bool = True):
-    """frames: (T,3,h,w) on the GPU, frame 0 = I-frame reconstruction. Returns per-P-frame stats."""
+def code_gop(net, frames: torch.Tensor, enable_amp: bool = True, bitstream_dir: str | None = None, tag: str = ""):
+    """frames: (T,3,h,w) on the GPU, frame 0 = I-frame reconstruction. Returns per-P-frame stats.
+    With `bitstream_dir` every frame is really coded (`VideoCompressor.encode`), written as a container file in the
+    record layout of tools/utils/encoder.py:61-68, read back and decoded; the decoder's frame must equal the encoder's."""
     h, w = frames.shape[-2:]
     refs = [pad(frames[0:1], 64)]
     stats = []
     for t in range(1, frames.shape[0]):
         x = pad(frames[t:t + 1], 64)
+        if bitstream_dir:
+            from .. import bitstream
+            rl = ref_list(refs)
+            enc = net.encode(x, rl)
+            flat = [s[0] for s in enc["strings"]]
+            shp = [(0, 128, *enc["shapes"][i // 2]) for i in range(4)]
+            path = os.path.join(bitstream_dir, f"{tag}frame{t:03d}.bin")
+            with open(path, "wb") as f:
+                nbytes = bitstream.write_records(f, flat, shp)
+            with open(path, "rb") as f:
+                strings, shapes = bitstream.read_records(f, 4)
+            recon = net.decode([[s] for s in strings], [shapes[0][2:], shapes[2][2:]], rl)
+            assert torch.equal(recon, enc["recon"]), "decoder / encoder reconstruction mismatch"
+            refs.append(recon)
+            rc, xc = crop(recon, (h, w)), crop(x, (h, w))
+            bpp = 8.0 * nbytes / (x.shape[-2] * x.shape[-1])
+            stats.append({"frame": t, "psnr": psnr(rc, xc), "bpp": bpp, "bpp_mv": 8.0 * (len(flat[0]) + len(flat[1])) / (x.shape[-2] * x.shape[-1]),
+                          "bpp_res": 8.0 * (len(flat[2]) + len(flat[3])) / (x.shape[-2] * x.shape[-1]), "bytes": nbytes})
+            continue
         recon, bpp_res, bpp_mv = net(x, ref_list(refs), enable_amp)
         refs.append(recon)                                   # padded reconstruction re-enters the list (:68)
         rc, xc = crop(recon, (h, w)), crop(x, (h, w))
@@ -50,6 +72,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--bitstream-dir", default=None, help="really encode / write / read / decode every frame into this directory")
     a = ap.parse_args()
     opt = {"model": "pnet", "pretrain": a.pretrain, "val_dataset": "synthetic", "class": "-", "enable_amp": True}
     if a.cfg:
@@ -72,7 +95,9 @@ def main():
     with torch.no_grad():
         for g in shard_gops(a.gops, world, rank):
             frames = make_gop(2000 + g, a.gop_size, a.height, a.width).to(dev)
-            for s in code_gop(net, frames, bool(opt["enable_amp"])):
+            if a.bitstream_dir:
+                os.makedirs(a.bitstream_dir, exist_ok=True)
+            for s in code_gop(net, frames, bool(opt["enable_amp"]), a.bitstream_dir, f"gop{g:03d}_"):
                 s["gop"] = g
                 stats.append(s)
     torch.cuda.synchronize()

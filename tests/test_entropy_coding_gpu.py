@@ -87,3 +87,44 @@ def test_forward_is_compress_flag(report):
     ac = m.last_ac_bpp
     report(f"is_compress: estimated bpp res/mv {float(br2):.4f}/{float(bm2):.4f}, coded {ac['res']:.4f}/{ac['mv']:.4f}")
     assert abs(ac["res"] - float(br2)) < 0.3 * float(br2) + 0.2 and abs(ac["mv"] - float(bm2)) < 0.3 * float(bm2) + 0.2
+
+
+def test_frame_encode_container_decode_roundtrip(report):
+    """VideoCompressor.encode -> container records (tools/utils/encoder.py:61-68 layout) -> decode: the decoder rebuilds
+    the encoder's closed-loop reconstruction bit for bit, and the container size is the coded rate"""
+    import io
+
+    from tdvc_amd import bitstream, synth
+    from tdvc_amd.model import VideoCompressor
+    net = VideoCompressor()
+    synth.fill_parameters(net)
+    net = net.cuda().eval()
+    H = W = 64
+    gop = synth.make_gop(77, 7, H, W).cuda()
+    refs = synth.ref_list([gop[0:1], gop[1:2], gop[2:3]])
+    x = gop[3:4]
+    enc = net.encode(x, refs)
+    flat = [s[0] for s in enc["strings"]]                                   # batch item 0 of [mv_y, mv_z, res_y, res_z]
+    shp = [(0, 128, *enc["shapes"][0]), (0, 128, *enc["shapes"][0]), (0, 128, *enc["shapes"][1]), (0, 128, *enc["shapes"][1])]
+    buf = io.BytesIO()
+    nbytes = bitstream.write_records(buf, flat, shp)
+    assert nbytes == buf.tell()
+    buf.seek(0)
+    strings, shapes = bitstream.read_records(buf, 4)
+    assert strings == flat and [tuple(s) for s in shapes] == shp
+    dec = net.decode([[strings[0]], [strings[1]], [strings[2]], [strings[3]]], [shapes[0][2:], shapes[2][2:]], refs)
+    assert torch.equal(dec, enc["recon"]), "decoder reconstruction differs from the encoder's"
+    rec, bpp_res, bpp_mv = net(x, refs, True)
+    coded_bpp = 8.0 * sum(len(s) for s in flat) / (H * W)
+    psnr = lambda a, b: float(10 * torch.log10(1.0 / ((a - b) ** 2).mean()))
+    report(f"encode/decode 64x64: container {nbytes} B, coded {coded_bpp:.4f} bpp vs estimated {float(bpp_res + bpp_mv):.4f} bpp; "
+           f"PSNR decode {psnr(dec, x):.3f} dB vs forward {psnr(rec, x):.3f} dB")
+    assert abs(coded_bpp - float(bpp_res + bpp_mv)) < 0.05 * float(bpp_res + bpp_mv) + 0.1
+    assert abs(psnr(dec, x) - psnr(rec, x)) < 0.3
+    # long payload escape of the container
+    big = [b"\\x01" * 70000]
+    b2 = io.BytesIO()
+    bitstream.write_records(b2, big, [(1, 2, 3, 4)])
+    b2.seek(0)
+    s2, sh2 = bitstream.read_records(b2, 1)
+    assert s2 == big and tuple(sh2[0]) == (1, 2, 3, 4)
