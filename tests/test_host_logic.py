@@ -1,5 +1,6 @@
 """CPU: host-side logic of the product (no GPU compute)."""
 import numpy as np
+import pytest
 import torch
 
 from tdvc_amd import ops
@@ -200,3 +201,28 @@ def test_training_sampler_matches_reference_rule():
     got = [(int(x[0, 0, 0]), [int(r[0, 0, 0]) for r in refs]) for x, refs in septuplet_samples(frames)]
     assert got == [(2, [1, 1, 1, 1]), (3, [1, 1, 2, 2]), (4, [1, 1, 2, 3]), (5, [1, 2, 3, 4]), (6, [1, 3, 4, 5]), (7, [1, 4, 5, 6]),
                    (7, [1, 1, 3, 5])]
+
+
+def test_bitstream_container_layout():
+    """record layout of tools/utils/encoder.py:61-68: `>4I` shape, native uint16 byte count, payload; long-payload escape"""
+    import io
+    import struct
+
+    from tdvc_amd import bitstream
+    strings = [b"abc", b"", bytes(range(256)) * 3]
+    shapes = [(0, 128, 4, 6), (0, 128, 1, 2), (1, 128, 17, 30)]
+    buf = io.BytesIO()
+    n = bitstream.write_records(buf, strings, shapes)
+    raw = buf.getvalue()
+    assert n == len(raw) == sum(16 + 2 + len(s) for s in strings)
+    assert struct.unpack(">4I", raw[:16]) == shapes[0] and int(np.frombuffer(raw[16:18], dtype=np.uint16)[0]) == 3 and raw[18:21] == b"abc"
+    buf.seek(0)
+    s2, sh2 = bitstream.read_records(buf, 3)
+    assert s2 == strings and [tuple(s) for s in sh2] == shapes
+    big = io.BytesIO()
+    bitstream.write_records(big, [b"x" * 65535], [(1, 2, 3, 4)])
+    assert len(big.getvalue()) == 16 + 2 + 4 + 65535
+    big.seek(0)
+    assert bitstream.read_records(big, 1)[0][0] == b"x" * 65535
+    with pytest.raises(ValueError):
+        bitstream.read_records(io.BytesIO(raw[:-1]), 3)
