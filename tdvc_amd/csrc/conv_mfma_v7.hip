@@ -40,7 +40,7 @@ static_assert(DMA7 * 8 * 1024 <= WLO7, "tile buffer");
 static_assert(8 * 32 * 144 <= WLO7, "epilogue scratch aliases a tile buffer");
 
 struct V7Extra {
-  int ntiles, prio;
+  int ntiles;
   const half_t* zeros;      // >= 16 bytes of zeros: the DMA source of out-of-image halo pixels
 };
 
@@ -192,7 +192,6 @@ __global__ __launch_bounds__(NTHR7, 1) void conv_mfma_v7_kernel(const ConvParams
 #pragma unroll
       for (int nt = 0; nt < NT7; ++nt) fb[buf][nt] = *reinterpret_cast<const half8*>(tb + (bq[nt][t] ^ (s2 * 32)));
     };
-    if (e.prio) __builtin_amdgcn_s_setprio(1);
     frag(0, 0);
 #pragma unroll
     for (int i = 0; i < 18; ++i) {
@@ -208,7 +207,6 @@ __global__ __launch_bounds__(NTHR7, 1) void conv_mfma_v7_kernel(const ConvParams
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       if (i < DMA7 && have_next) issue_one(i, nbuf);
     }
-    if (e.prio) __builtin_amdgcn_s_setprio(0);
     ST7(3);
     stores_in_flight = false;
     if (ch != nchunks - 1) continue;
@@ -258,10 +256,6 @@ int launch_conv_v7(const ConvParams& p, int cout_blocks, int N, hipStream_t st) 
   V7Extra e;
   e.ntiles = q.tiles_x * tiles_y;
   e.zeros = zeros;
-  {
-    static const int prio = getenv("TDVC_CONV_PRIO") ? atoi(getenv("TDVC_CONV_PRIO")) : 0;
-    e.prio = prio;
-  }
   q.slope = convk::conv_simple_slope(p);
   int gx = 256 / (cout_blocks * N);
   if (gx < 1) gx = 1;
