@@ -199,8 +199,9 @@ extern "C" void tdvc_debug_set_stamp_buffer_v3(void* buf, int cap_blocks) { g_st
 bool conv_v3_eligible(const tdvc_conv_desc* d, int Ho, int Wo) {
   static const bool off = getenv("TDVC_CONV_NO_V3") != nullptr || getenv("TDVC_CONV_V1") != nullptr;
   if (off) return false;
+  const long minpix = 256;        // below: a handful of tiles, the direct kernel's shorter prologue wins
   return d->ck == 32 && d->stride == 1 && d->ntaps >= 2 && d->ntaps <= WLOADS && d->kh <= 3 && d->kw <= 3 && d->cout >= 64 &&
-         d->x.C >= 32 && !d->square_input && ((long)Ho * Wo >= 2048 || d->s2d);
+         d->x.C >= 32 && !d->square_input && ((long)Ho * Wo * d->x.N >= minpix || d->s2d);
 }
 
 int launch_conv_v3(const ConvParams& p, int cout_blocks, int N, hipStream_t st) {
