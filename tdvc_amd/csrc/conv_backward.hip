@@ -63,13 +63,13 @@ constexpr int PSX = WG_CI * 2 + 16;             // ... of the X tile (80)
 struct WgradParams {
   FMap g, x;
   int Ho, Wo, stride, pad;
-  int ntaps_all, tap0, ntaps;                   // this launch's tap group [tap0, tap0 + ntaps) of the layer's tap list
+  int ntaps_all;                                // taps of the layer; blockIdx.z picks a group of <= WG_MAXT of them
   int8_t tap_dy[TDVC_MAX_TAPS], tap_dx[TDVC_MAX_TAPS];
   int co_tiles, ci_tiles;
   int blocks_x, blocks_y, nblocks;              // pixel blocks per image, total over the batch
   int tih, tiw;                                 // X tile extent in pixels
   int square_x;                                 // contract with x^2 (GDN norm pool: dgamma = sum dnorm * x^2)
-  float* work;                                  // [P][co_tiles*64][ci_tiles*32][ntaps_all]
+  float* work;                                  // [P][ntaps_all][co_tiles*64][ci_tiles*32]
 };
 
 typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cit = blockIdx.x % p.ci_tiles, cot = blockIdx.x / p.ci_tiles;
   const int worker = blockIdx.y, nworkers = gridDim.y;
+  const int tap0 = blockIdx.z * WG_MAXT, ntaps_g = min(WG_MAXT, p.ntaps_all - tap0);      // this workgroup's tap group
   const int co0 = cot * WG_CO, ci0 = cit * WG_CI;
 
   // taps of this wave: wave, wave + 4, wave + 8 (inside the launch's group)
@@ -174,8 +175,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int ai = 0; ai < 3; ++ai) {
           const int t = wave + 4 * ai;
-          if (t < p.ntaps) {                                         // wave-uniform
-            const int dy = p.tap_dy[p.tap0 + t], dx = p.tap_dx[p.tap0 + t];
+          if (t < ntaps_g) {                                         // wave-uniform
+            const int dy = p.tap_dy[tap0 + t], dx = p.tap_dx[tap0 + t];
             const int xk = (yy * p.stride + dy) * p.tiw + (kh * 16 + 8 * khalf + rq) * p.stride + dx;
             const unsigned char* bp = xt + xk * PSX + colbase * 2;
             const half4 lo = tr_read(bp), hi = tr_read(bp + 4 * p.stride * PSX);
@@ -188,19 +189,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
   }
   // ---- partial dW block -> workspace[worker][co][ci][tap]
-  const int CIW = p.ci_tiles * WG_CI;
-  float* wk = p.work + (long)worker * (p.co_tiles * WG_CO) * CIW * p.ntaps_all;
+  const int CIW = p.ci_tiles * WG_CI, COW = p.co_tiles * WG_CO;
+  float* wk = p.work + (long)worker * p.ntaps_all * COW * CIW;       // [worker][tap][co][ci]: a half wave stores 128 contiguous bytes
   const int col = lane & 31, hh = lane >> 5;
 #pragma unroll
   for (int ai = 0; ai < 3; ++ai) {
     const int t = wave + 4 * ai;
-    if (t < p.ntaps) {
+    if (t < ntaps_g) {
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-          wk[((long)(co0 + m * 32 + row) * CIW + (ci0 + col)) * p.ntaps_all + p.tap0 + t] = acc[ai][m][i];
+          wk[((long)(tap0 + t) * COW + (co0 + m * 32 + row)) * CIW + (ci0 + col)] = acc[ai][m][i];
         }
     }
   }
@@ -215,14 +216,14 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ work, int nworkers
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)cout * cin * ntaps;
   if (i >= total) return;
-  const int t = (int)(i % ntaps);
-  const long q = i / ntaps;
-  const int ci = (int)(q % cin), co = (int)(q / cin);
+  const int ci = (int)(i % cin);                          // fastest index = ci: coalesced reads of the partials
+  const long q = i / cin;
+  const int co = (int)(q % cout), t = (int)(q / cout);
   const int ro = row_off[co], cf = chan_off[ci];
   if (ro < 0 || cf < 0) return;
   float s = 0.f;
-  const long stride = (long)COW * CIW * ntaps;
-  const long off = ((long)co * CIW + ci) * ntaps + t;
+  const long stride = (long)ntaps * COW * CIW;
+  const long off = ((long)t * COW + co) * CIW + ci;
   for (int w = 0; w < nworkers; ++w) s += work[w * stride + off];
   dw[(long)ro + cf + tap_off[t]] += s * scale;
 }
@@ -243,11 +244,14 @@ extern "C" int tdvc_pack_conv_weights_indexed(const float* w, const int32_t* row
   return tdvc_launch_status("tdvc_pack_conv_weights_indexed");
 }
 
-static int wgrad_workers(int co_tiles, int ci_tiles, int groups, int nblocks) {
+static int wgrad_workers(int co_tiles, int ci_tiles, int groups, int nblocks, int ntaps) {
   int w = 1024 / (co_tiles * ci_tiles * groups);      // ~4 workgroups per CU over the whole launch
-  if (w < 1) w = 1;
+  const long dw_bytes = (long)co_tiles * WG_CO * ci_tiles * WG_CI * ntaps * 4;
+  const long cap = (16L << 20) / dw_bytes;            // partial sums are written and re-read once: keep them <= 16 MB per layer
+  if (w > cap) w = (int)cap;
   if (w > nblocks) w = nblocks;
-  if (w > 256) w = 256;                               // bounds the partial-sum workspace (workers x |dW| floats)
+  if (w > 256) w = 256;
+  if (w < 1) w = 1;
   return w;
 }
 
@@ -255,7 +259,7 @@ extern "C" int64_t tdvc_conv_wgrad_work_floats(int cout, int cin, int ntaps, int
   if (cout <= 0 || cin <= 0 || ntaps <= 0 || ntaps > TDVC_MAX_TAPS || N <= 0 || Ho <= 0 || Wo <= 0) return TDVC_EINVAL;
   const int co_tiles = (cout + WG_CO - 1) / WG_CO, ci_tiles = (cin + WG_CI - 1) / WG_CI, groups = (ntaps + WG_MAXT - 1) / WG_MAXT;
   const int nblocks = N * ((Ho + WG_TH - 1) / WG_TH) * ((Wo + WG_TW - 1) / WG_TW);
-  return (int64_t)wgrad_workers(co_tiles, ci_tiles, groups, nblocks) * co_tiles * WG_CO * ci_tiles * WG_CI * ntaps;
+  return (int64_t)wgrad_workers(co_tiles, ci_tiles, groups, nblocks, ntaps) * co_tiles * WG_CO * ci_tiles * WG_CI * ntaps;
 }
 
 extern "C" int tdvc_conv_wgrad(const tdvc_fmap* g, const tdvc_fmap* x, int cout, int kh, int kw, int stride, int pad,
@@ -287,18 +291,14 @@ extern "C" int tdvc_conv_wgrad(const tdvc_fmap* g, const tdvc_fmap* x, int cout,
   p.work = work;
   p.square_x = square_x;
   const int groups = (ntaps + WG_MAXT - 1) / WG_MAXT;
-  const int workers = wgrad_workers(p.co_tiles, p.ci_tiles, groups, p.nblocks);
+  const int workers = wgrad_workers(p.co_tiles, p.ci_tiles, groups, p.nblocks, ntaps);
   const int xl = (p.tih * p.tiw * (WG_CI / 8) + 255) / 256;
   TDVC_CHECK(xl <= 18, "tdvc_conv_wgrad: X tile of %dx%d pixels needs %d pieces per thread (max 18)", p.tih, p.tiw, xl);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   auto go = [&](auto kern) -> int {
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err != hipSuccess) { tdvc_set_error("tdvc_conv_wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(err)); return (int)err; }
-    for (int gI = 0; gI < groups; ++gI) {
-      p.tap0 = gI * WG_MAXT;
-      p.ntaps = ntaps - p.tap0 < WG_MAXT ? ntaps - p.tap0 : WG_MAXT;
-      hipLaunchKernelGGL(kern, dim3(p.co_tiles * p.ci_tiles, workers), dim3(256), lds, st, p);
-    }
+    hipLaunchKernelGGL(kern, dim3(p.co_tiles * p.ci_tiles, workers, groups), dim3(256), lds, st, p);
     return 0;
   };
   const int rc = xl <= 6 ? go(&conv_wgrad_kernel<6>) : (xl <= 9 ? go(&conv_wgrad_kernel<9>) : go(&conv_wgrad_kernel<18>));

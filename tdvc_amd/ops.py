@@ -302,6 +302,7 @@ def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, 
                             flops=2.0 * x.N * Ho * Wo * pc.cout * x.C * len(pc.taps),
                             flops_real=(x.N * Ho * Wo * pc.flops_per_px) if pc.s2d else 2.0 * x.N * Ho * Wo * pc.cout * pc.cin_real * len(pc.taps),
                             bytes=2.0 * x.N * (x.H * x.W * x.C + Ho * Wo * pc.cout * (4 if pc.shuffle else 1) / (4 if pc.shuffle else 1))))
+        _rec("conv", x, pc, None if nchw_out is not None else ret, act, slope, res, res2, gdn, aux, square, nchw_out)
         return ret
     L.check(L.lib().tdvc_conv2d(C.byref(d), _stream()), "conv2d")
     _rec("conv", x, pc, None if nchw_out is not None else ret, act, slope, res, res2, gdn, aux, square, nchw_out)
@@ -371,9 +372,17 @@ def conv_wgrad(pc: PackedConv, g: FM, x: FM, dw: torch.Tensor, scale=1.0, square
     dy = (C.c_int8 * len(taps))(*[t[0] for t in taps])
     dxs = (C.c_int8 * len(taps))(*[t[1] for t in taps])
     dg, dxd = g.desc(), x.desc()
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     L.check(lib.tdvc_conv_wgrad(C.byref(dg), C.byref(dxd), pc.cout, o["kh"], o["kw"], o["stride"], o["pad"], len(taps), dy, dxs,
                                 tb.row_off.data_ptr(), tb.chan_off.data_ptr(), tb.tap_off.data_ptr(), int(square_x), scale, dw.data_ptr(),
                                 work.data_ptr(), nwork, _stream()), "conv_wgrad")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(dict(kernel="conv_wgrad", shape=f"{o['kh']}x{o['kw']} s{o['stride']} {x.C}->{pc.cout} @{x.N}x{x.H}x{x.W}", e0=e0, e1=e1,
+                            flops=2.0 * x.N * Ho * Wo * pc.cout * x.C * len(taps), flops_real=2.0 * x.N * Ho * Wo * pc.cout * pc.cin_real * len(taps),
+                            bytes=0.0))
 
 
 def conv_bgrad(pc: PackedConv, g: FM, db: torch.Tensor, scale=1.0) -> None:

@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""diagnostic: per-launch table of the conv kernels (forward, data-gradient and weight-gradient launches) of one training
+step at 4 x 256x256 (HIP events on the launch stream)"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tdvc_amd import ops  # noqa: E402
+from tdvc_amd.model import VideoCompressor  # noqa: E402
+from tdvc_amd.synth import fill_parameters, make_gop, ref_list  # noqa: E402
+from tdvc_amd.train import TrainStep  # noqa: E402
+
+dev = torch.device("cuda", 0)
+m = VideoCompressor()
+fill_parameters(m)
+m = m.to(dev).train()
+xs, rs = [], []
+for i in range(4):
+    g = make_gop(1000 + i, 7, 256, 256).to(dev)
+    xs.append(g[3:4])
+    rs.append(ref_list([g[0:1], g[1:2], g[2:3]]))
+x, refs = torch.cat(xs), torch.cat(rs)
+step = TrainStep(m, loss_scale=128.0)
+for _ in range(2):
+    step(x, refs)
+torch.cuda.synchronize()
+ops.PROFILE = []
+step(x, refs)
+torch.cuda.synchronize()
+prof, ops.PROFILE = ops.PROFILE, None
+agg = {}
+for r in prof:
+    k = (r["kernel"], r["shape"])
+    a = agg.setdefault(k, [0, 0.0, 0.0])
+    a[0] += 1
+    a[1] += r["e0"].elapsed_time(r["e1"])
+    a[2] += r["flops_real"]
+tot = {}
+for (k, sh), (n, ms, fl) in agg.items():
+    tot[k] = tot.get(k, 0.0) + ms
+print({k: round(v, 2) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])})
+for (k, sh), (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+    print(f"{ms:7.3f} ms  n={n:3d}  {ms / n * 1e3:7.1f} us/launch  {fl / ms / 1e9:7.1f} TF  {k:18s} {sh}")
