@@ -272,6 +272,21 @@ int tdvc_round_symbols(const tdvc_fmap* z, const float* median, int32_t* out, vo
 int tdvc_pack_conv_weights_indexed(const float* w, const int32_t* row_off, const int32_t* chan_off, const int32_t* tap_off,
                                    const uint8_t* row_mask, const uint8_t* chan_mask, const uint8_t* tap_mask,
                                    int cout, int cin, int ntaps, int ck, void* dst, void* stream);
+/* The same for many layers in one launch (after an optimizer step every packed layer follows its parameters).  `jobs`
+ * and `block_start` (njobs + 1 prefix sums of tdvc_pack_job_blocks) are DEVICE arrays; a job with bias_src also
+ * gathers its bias: bias_dst[i] = bias_src[bias_perm ? bias_perm[i] : i], i < cout. */
+typedef struct tdvc_pack_job {
+  const float* w;
+  const int32_t *row_off, *chan_off, *tap_off;
+  const uint8_t *row_mask, *chan_mask, *tap_mask;
+  void* dst;
+  const float* bias_src;
+  float* bias_dst;
+  const int32_t* bias_perm;
+  int32_t cout, cin, ntaps, ck;
+} tdvc_pack_job;
+int64_t tdvc_pack_job_blocks(int cout, int cin, int ntaps, int ck);
+int tdvc_pack_conv_weights_batch(const tdvc_pack_job* jobs, const int32_t* block_start, int njobs, int total_blocks, void* stream);
 /* dW[row_off[co] + chan_off[ci] + tap_off[t]] += scale * sum_{n,oy,ox} g[n,oy,ox,co] * x[n, oy*stride + dy_t - pad, ox*stride + dx_t - pad, ci]
  * for the forward conv y = conv(x, W); g = dL/dy (fp16 fmap, >= cout channels; for a sub-pixel conv the un-shuffled
  * gradient in packed-row order), dW the fp32 parameter gradient.  row_off[cout] / chan_off[x.C] / tap_off[ntaps] are the

@@ -194,45 +194,72 @@ __global__ void reduce_groups_kernel(const float* partial, int N, int nblocks, i
   out[i] += s;
 }
 
-// Backward of se_gate_kernel (gate = sigmoid(W2 relu(W1 mean + b1) + b2)): one workgroup, batch items in order.
+// Backward of se_gate_kernel (gate = sigmoid(W2 relu(W1 mean + b1) + b2)): one workgroup; W1 / W2 are staged in LDS, the
+// batch items are walked in order and the parameter gradients leave the registers once.
 // dmean[n][c] (written), dW1 / db1 / dW2 / db2 += scale * ...
 __global__ __launch_bounds__(1024) void se_gate_backward_kernel(const float* partial, int nblocks, float inv_count, int N, int C_, int Cmid,
                                                                 const float* w1, const float* b1, const float* w2, const float* b2,
                                                                 const float* gate, const float* dgate, float scale, float* dmean,
                                                                 float* dw1, float* db1, float* dw2, float* db2) {
-  __shared__ float mean[256], ds[256];
-  __shared__ float mid[32], dmid[32];
+  extern __shared__ float sm[];
+  float* w1s = sm;                       // [Cmid][C_]
+  float* w2s = w1s + Cmid * C_;          // [C_][Cmid + 1]
+  float* mean = w2s + C_ * (Cmid + 1);   // [N][C_]
+  float* ds = mean + N * C_;             // [N][C_]
+  float* mid = ds + N * C_;              // [32]
+  float* dmid = mid + 32;                // [32]
   const int tid = threadIdx.x;
+  for (int i = tid; i < Cmid * C_; i += 1024) {
+    w1s[i] = w1[i];
+    w2s[(i / Cmid) * (Cmid + 1) + (i % Cmid)] = w2[i];
+  }
+  for (int i = tid; i < N * C_; i += 1024) {
+    const int n = i / C_, c = i - n * C_;
+    float s = 0.f;
+#pragma unroll 8
+    for (int b = 0; b < nblocks; ++b) s += partial[((long)n * nblocks + b) * C_ + c];
+    mean[i] = s * inv_count;
+    const float gt = gate[i];
+    ds[i] = dgate[i] * gt * (1.f - gt);                                  // d pre-sigmoid
+  }
+  float a1[32], a2[32], ab1 = 0.f, ab2 = 0.f;                            // dW1[j][tid], dW2[tid][j], db1[tid], db2[tid]
+#pragma unroll
+  for (int j = 0; j < 32; ++j) { a1[j] = 0.f; a2[j] = 0.f; }
+  __syncthreads();
   for (int n = 0; n < N; ++n) {
-    if (tid < C_) {
-      float s = 0.f;
-      for (int b = 0; b < nblocks; ++b) s += partial[((long)n * nblocks + b) * C_ + tid];
-      mean[tid] = s * inv_count;
-      const float gt = gate[(long)n * C_ + tid];
-      ds[tid] = dgate[(long)n * C_ + tid] * gt * (1.f - gt);             // d pre-sigmoid
-    }
-    __syncthreads();
+    const float* mn = mean + n * C_;
+    const float* dn = ds + n * C_;
     if (tid < Cmid) {
-      float s = b1[tid];
-      for (int c = 0; c < C_; ++c) s += w1[tid * C_ + c] * mean[c];
+      float s = b1[tid], d = 0.f;
+      for (int c = 0; c < C_; ++c) { s += w1s[tid * C_ + c] * mn[c]; d += w2s[c * (Cmid + 1) + tid] * dn[c]; }
       mid[tid] = s > 0.f ? s : 0.f;
-      float d = 0.f;
-      for (int c = 0; c < C_; ++c) d += w2[c * Cmid + tid] * ds[c];
       dmid[tid] = s > 0.f ? d : 0.f;
-      db1[tid] += scale * dmid[tid];
+      ab1 += s > 0.f ? d : 0.f;
     }
     __syncthreads();
     if (tid < C_) {
-      db2[tid] += scale * ds[tid];
+      ab2 += dn[tid];
       float d = 0.f;
-      for (int j = 0; j < Cmid; ++j) {
-        dw2[tid * Cmid + j] += scale * ds[tid] * mid[j];
-        dw1[j * C_ + tid] += scale * dmid[j] * mean[tid];
-        d += w1[j * C_ + tid] * dmid[j];
-      }
+#pragma unroll
+      for (int j = 0; j < 32; ++j)
+        if (j < Cmid) {
+          a2[j] += dn[tid] * mid[j];
+          a1[j] += dmid[j] * mn[tid];
+          d += w1s[j * C_ + tid] * dmid[j];
+        }
       dmean[(long)n * C_ + tid] = d;
     }
     __syncthreads();
+  }
+  if (tid < Cmid) db1[tid] += scale * ab1;
+  if (tid < C_) {
+    db2[tid] += scale * ab2;
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+      if (j < Cmid) {
+        dw2[tid * Cmid + j] += scale * a2[j];
+        dw1[j * C_ + tid] += scale * a1[j];
+      }
   }
 }
 
@@ -736,7 +763,7 @@ extern "C" int tdvc_pixel_unshuffle(const tdvc_fmap* y, const tdvc_fmap* out, vo
   return tdvc_launch_status("tdvc_pixel_unshuffle");
 }
 
-extern "C" int64_t tdvc_bias_grad_work_floats(int N, int C_) { return (int64_t)N * 64 * C_; }
+extern "C" int64_t tdvc_bias_grad_work_floats(int N, int C_) { return (int64_t)N * 256 * C_; }
 
 extern "C" int tdvc_bias_grad(const tdvc_fmap* g, int nvalid, const int32_t* dst_index, float scale, float* db, float* work, int64_t work_floats, void* stream) {
   TDVC_CHECK(g && db && work && fmap_any(*g) && (g->C % 8) == 0 && nvalid >= 1 && nvalid <= g->C, "tdvc_bias_grad: bad arguments");
@@ -764,7 +791,7 @@ extern "C" int tdvc_clamp01_backward(const tdvc_fmap* g, const tdvc_fmap* y, voi
   return tdvc_launch_status("tdvc_clamp01_backward");
 }
 
-extern "C" int64_t tdvc_gate_backward_work_floats(int N, int C_) { return (int64_t)N * 64 * C_; }
+extern "C" int64_t tdvc_gate_backward_work_floats(int N, int C_) { return (int64_t)N * 256 * C_; }
 
 extern "C" int tdvc_gate_backward(const tdvc_fmap* g, const tdvc_fmap* a, const float* gate, const tdvc_fmap* da, float* dgate, float* work,
                                   int64_t work_floats, void* stream) {
@@ -773,7 +800,7 @@ extern "C" int tdvc_gate_backward(const tdvc_fmap* g, const tdvc_fmap* a, const 
   if (da) TDVC_CHECK(fmap_any(*da) && same_geom(*g, *da) && da->C == g->C, "tdvc_gate_backward: bad da");
   TDVC_CHECK(work_floats >= tdvc_gate_backward_work_floats(g->N, g->C), "tdvc_gate_backward: workspace too small");
   const long npix = (long)g->H * g->W;
-  const int nblocks = (int)(npix / 4096 < 1 ? 1 : (npix / 4096 > 64 ? 64 : npix / 4096));
+  const int nblocks = (int)(npix / 256 < 1 ? 1 : (npix / 256 > 256 ? 256 : npix / 256));
   hipLaunchKernelGGL(gate_backward_kernel, dim3(nblocks, g->N), dim3(256), 0, ST(stream), to_dev(*g), to_dev(*a), gate, da ? to_dev(*da) : null_fmap(), work, nblocks);
   hipLaunchKernelGGL(reduce_groups_kernel, dim3((g->N * g->C + 255) / 256), dim3(256), 0, ST(stream), work, g->N, nblocks, g->C, dgate);
   return tdvc_launch_status("tdvc_gate_backward");
@@ -784,7 +811,11 @@ extern "C" int tdvc_se_gate_backward(const float* partial, int nblocks, float in
                                      float* dw1, float* db1, float* dw2, float* db2, void* stream) {
   TDVC_CHECK(partial && w1 && b1 && w2 && b2 && gate && dgate && dmean && dw1 && db1 && dw2 && db2 && C_ <= 256 && Cmid <= 32 && N >= 1,
              "tdvc_se_gate_backward: bad arguments");
-  hipLaunchKernelGGL(se_gate_backward_kernel, dim3(1), dim3(1024), 0, ST(stream), partial, nblocks, inv_count, N, C_, Cmid, w1, b1, w2, b2, gate, dgate,
+  const size_t lds = sizeof(float) * ((size_t)Cmid * C_ + (size_t)C_ * (Cmid + 1) + 2 * (size_t)N * C_ + 64);
+  TDVC_CHECK(lds <= 160 * 1024, "tdvc_se_gate_backward: batch too large for one workgroup's LDS");
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(se_gate_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(se_gate_backward_kernel, dim3(1), dim3(1024), lds, ST(stream), partial, nblocks, inv_count, N, C_, Cmid, w1, b1, w2, b2, gate, dgate,
                      scale, dmean, dw1, db1, dw2, db2);
   return tdvc_launch_status("tdvc_se_gate_backward");
 }

@@ -17,13 +17,11 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------ packing
-__global__ void pack_indexed_kernel(const float* __restrict__ w, const int* __restrict__ row_off, const int* __restrict__ chan_off,
-                                    const int* __restrict__ tap_off, const unsigned char* __restrict__ row_mask,
-                                    const unsigned char* __restrict__ chan_mask, const unsigned char* __restrict__ tap_mask,
-                                    int cout, int cin, int ntaps, int ck,
-                                    int nchunks, int steps, long total, half_t* __restrict__ out) {
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;          // one thread per 8 packed halves
-  if (e >= total) return;
+__device__ __forceinline__ void pack_indexed_item(const float* __restrict__ w, const int* __restrict__ row_off, const int* __restrict__ chan_off,
+                                                  const int* __restrict__ tap_off, const unsigned char* __restrict__ row_mask,
+                                                  const unsigned char* __restrict__ chan_mask, const unsigned char* __restrict__ tap_mask,
+                                                  int cout, int cin, int ntaps, int ck,
+                                                  int nchunks, int steps, long e, half_t* __restrict__ out) {
   const int lane = (int)(e & 63);
   long q = e >> 6;
   const int s = (int)(q % steps); q /= steps;
@@ -51,6 +49,36 @@ __global__ void pack_indexed_kernel(const float* __restrict__ w, const int* __re
     }
   }
   *reinterpret_cast<half8*>(out + e * 8) = o;
+}
+
+__global__ void pack_indexed_kernel(const float* __restrict__ w, const int* __restrict__ row_off, const int* __restrict__ chan_off,
+                                    const int* __restrict__ tap_off, const unsigned char* __restrict__ row_mask,
+                                    const unsigned char* __restrict__ chan_mask, const unsigned char* __restrict__ tap_mask,
+                                    int cout, int cin, int ntaps, int ck,
+                                    int nchunks, int steps, long total, half_t* __restrict__ out) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;          // one thread per 8 packed halves
+  if (e >= total) return;
+  pack_indexed_item(w, row_off, chan_off, tap_off, row_mask, chan_mask, tap_mask, cout, cin, ntaps, ck, nchunks, steps, e, out);
+}
+
+// Every packed layer of a model in one launch: block_start[j] .. block_start[j+1] are the 256-item blocks of job j.
+__global__ void pack_batch_kernel(const tdvc_pack_job* __restrict__ jobs, const int* __restrict__ block_start, int njobs) {
+  int lo = 0, hi = njobs;                                              // last job with block_start <= blockIdx.x
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (block_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const tdvc_pack_job jb = jobs[lo];
+  const int lb = blockIdx.x - block_start[lo];
+  const int ck8 = jb.ck >> 3, nchunks = (jb.cin + jb.ck - 1) / jb.ck, steps = (jb.ntaps * ck8 + 1) / 2;
+  const int cot = jb.cout <= 32 ? 1 : 2 * ((jb.cout + 63) / 64);      // 32-row tiles of the padded cout
+  const long total = (long)cot * nchunks * steps * 64;
+  const long e = (long)lb * 256 + threadIdx.x;
+  if (e < total)
+    pack_indexed_item(jb.w, jb.row_off, jb.chan_off, jb.tap_off, jb.row_mask, jb.chan_mask, jb.tap_mask, jb.cout, jb.cin, jb.ntaps, jb.ck, nchunks,
+                      steps, e, reinterpret_cast<half_t*>(jb.dst));
+  if (lb == 0 && jb.bias_src)
+    for (int i = threadIdx.x; i < jb.cout; i += 256) jb.bias_dst[i] = jb.bias_src[jb.bias_perm ? jb.bias_perm[i] : i];
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad
@@ -145,6 +173,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
   };
 
+  // this wave's taps: wave, wave + 4, wave + 8 of the group; an absent tap reads tap 0's window and skips its MFMAs
+  int xoff[3];
+  bool tv[3];
+#pragma unroll
+  for (int ai = 0; ai < 3; ++ai) {
+    const int t = wave + 4 * ai;
+    tv[ai] = t < ntaps_g;
+    const int tt = tap0 + (tv[ai] ? t : 0);
+    xoff[ai] = (p.tap_dy[tt] * p.tiw + p.tap_dx[tt]) * PSX;
+  }
+  const unsigned char* abase = gt + (8 * khalf + rq) * PSG + colbase * 2;
+  const unsigned char* bbase = xt + (8 * khalf + rq) * p.stride * PSX + colbase * 2;
   if (worker < p.nblocks) prefetch(worker);
   for (int blk = worker; blk < p.nblocks; blk += nworkers) {
     __syncthreads();                                                // previous block's reads are done
@@ -160,31 +200,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
     __syncthreads();
     if (blk + nworkers < p.nblocks) prefetch(blk + nworkers);
-    // ---- contraction: k-steps of 16 consecutive output pixels of one row
-    for (int yy = 0; yy < WG_TH; ++yy) {
-#pragma unroll
-      for (int kh = 0; kh < WG_TW / 16; ++kh) {
-        const int pk = yy * WG_TW + kh * 16 + 8 * khalf + rq;        // dY pixel of the row this lane addresses (j = 0..3)
-        half8 a[2];
+    // ---- contraction: k-steps of 16 consecutive output pixels of one row.  Fragments of step ks+1 are read while the
+    // MFMAs of step ks run: with one workgroup per CU nothing else hides the LDS latency.
+    {
+      constexpr int KS = WG_TH * (WG_TW / 16);
+      auto load = [&](int ks, half8 (&a)[2], half8 (&b)[3]) {
+        const int yy = ks / (WG_TW / 16), kh = ks % (WG_TW / 16);
+        const unsigned char* ap = abase + (yy * WG_TW + kh * 16) * PSG;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-          const unsigned char* ap = gt + pk * PSG + (m * 32 + colbase) * 2;
-          const half4 lo = tr_read(ap), hi = tr_read(ap + 4 * PSG);
+          const half4 lo = tr_read(ap + m * 64), hi = tr_read(ap + m * 64 + 4 * PSG);
           a[m] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
+        const unsigned char* bp = bbase + ((yy * p.stride) * p.tiw + kh * 16 * p.stride) * PSX;
 #pragma unroll
         for (int ai = 0; ai < 3; ++ai) {
-          const int t = wave + 4 * ai;
-          if (t < ntaps_g) {                                         // wave-uniform
-            const int dy = p.tap_dy[tap0 + t], dx = p.tap_dx[tap0 + t];
-            const int xk = (yy * p.stride + dy) * p.tiw + (kh * 16 + 8 * khalf + rq) * p.stride + dx;
-            const unsigned char* bp = xt + xk * PSX + colbase * 2;
-            const half4 lo = tr_read(bp), hi = tr_read(bp + 4 * p.stride * PSX);
-            const half8 b = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-            for (int m = 0; m < 2; ++m) acc[ai][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b, acc[ai][m], 0, 0, 0);
-          }
+          const half4 lo = tr_read(bp + xoff[ai]), hi = tr_read(bp + xoff[ai] + 4 * p.stride * PSX);
+          b[ai] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
+      };
+      auto fma = [&](const half8 (&a)[2], const half8 (&b)[3]) {
+#pragma unroll
+        for (int ai = 0; ai < 3; ++ai)
+          if (tv[ai]) {                                              // wave-uniform
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[ai][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[ai], acc[ai][m], 0, 0, 0);
+          }
+      };
+      half8 a0[2], b0[3], a1[2], b1[3];
+      load(0, a0, b0);
+      for (int ks = 0; ks < KS; ks += 2) {
+        load(ks + 1, a1, b1);
+        fma(a0, b0);
+        if (ks + 2 < KS) load(ks + 2, a0, b0);
+        fma(a1, b1);
       }
     }
   }
@@ -213,18 +262,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 __global__ void wgrad_reduce_kernel(const float* __restrict__ work, int nworkers, int COW, int CIW, int ntaps, const int* __restrict__ row_off,
                                     const int* __restrict__ chan_off, const int* __restrict__ tap_off, int cout, int cin, float scale,
                                     float* __restrict__ dw) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  // 64 elements per workgroup, 4 worker slices per element (fixed order: the sum is reproducible)
+  __shared__ float part[4][64];
+  const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + e;
   const long total = (long)cout * cin * ntaps;
-  if (i >= total) return;
-  const int ci = (int)(i % cin);                          // fastest index = ci: coalesced reads of the partials
-  const long q = i / cin;
+  const bool live = i < total;
+  const int ci = live ? (int)(i % cin) : 0;               // fastest index = ci: coalesced reads of the partials
+  const long q = live ? i / cin : 0;
   const int co = (int)(q % cout), t = (int)(q / cout);
-  const int ro = row_off[co], cf = chan_off[ci];
-  if (ro < 0 || cf < 0) return;
-  float s = 0.f;
   const long stride = (long)ntaps * COW * CIW;
   const long off = ((long)t * COW + co) * CIW + ci;
-  for (int w = 0; w < nworkers; ++w) s += work[w * stride + off];
+  float s = 0.f;
+  if (live) {
+#pragma unroll 8
+    for (int w = sl; w < nworkers; w += 4) s += work[w * stride + off];
+  }
+  part[sl][e] = s;
+  __syncthreads();
+  if (sl != 0 || !live) return;
+  const int ro = row_off[co], cf = chan_off[ci];
+  if (ro < 0 || cf < 0) return;
+  s = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
   dw[(long)ro + cf + tap_off[t]] += s * scale;
 }
 
@@ -242,6 +301,17 @@ extern "C" int tdvc_pack_conv_weights_indexed(const float* w, const int32_t* row
   hipLaunchKernelGGL(pack_indexed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      w, row_off, chan_off, tap_off, row_mask, chan_mask, tap_mask, cout, cin, ntaps, ck, nchunks, steps, total, reinterpret_cast<half_t*>(dst));
   return tdvc_launch_status("tdvc_pack_conv_weights_indexed");
+}
+
+extern "C" int64_t tdvc_pack_job_blocks(int cout, int cin, int ntaps, int ck) {
+  const int64_t bytes = tdvc_conv_packed_bytes(cout, cin, ntaps, ck);
+  return bytes > 0 ? (bytes / 16 + 255) / 256 : bytes;
+}
+
+extern "C" int tdvc_pack_conv_weights_batch(const tdvc_pack_job* jobs, const int32_t* block_start, int njobs, int total_blocks, void* stream) {
+  TDVC_CHECK(jobs && block_start && njobs >= 1 && total_blocks >= 1, "tdvc_pack_conv_weights_batch: bad arguments");
+  hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), jobs, block_start, njobs);
+  return tdvc_launch_status("tdvc_pack_conv_weights_batch");
 }
 
 static int wgrad_workers(int co_tiles, int ci_tiles, int groups, int nblocks, int ntaps) {
@@ -304,7 +374,7 @@ extern "C" int tdvc_conv_wgrad(const tdvc_fmap* g, const tdvc_fmap* x, int cout,
   const int rc = xl <= 6 ? go(&conv_wgrad_kernel<6>) : (xl <= 9 ? go(&conv_wgrad_kernel<9>) : go(&conv_wgrad_kernel<18>));
   if (rc) return rc;
   const long total = (long)cout * cin * ntaps;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, work, workers, p.co_tiles * WG_CO,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, work, workers, p.co_tiles * WG_CO,
                      p.ci_tiles * WG_CI, ntaps, row_off, chan_off, tap_off, cout, cin, scale, dw);
   return tdvc_launch_status("tdvc_conv_wgrad");
 }

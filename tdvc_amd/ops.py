@@ -194,6 +194,78 @@ def _pack_from_tables(wsrc: torch.Tensor, tb: convpack.PackTables, dst: torch.Te
     return dst
 
 
+class _PackJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("row_off", C.c_void_p), ("chan_off", C.c_void_p), ("tap_off", C.c_void_p),
+                ("row_mask", C.c_void_p), ("chan_mask", C.c_void_p), ("tap_mask", C.c_void_p), ("dst", C.c_void_p),
+                ("bias_src", C.c_void_p), ("bias_dst", C.c_void_p), ("bias_perm", C.c_void_p),
+                ("cout", C.c_int32), ("cin", C.c_int32), ("ntaps", C.c_int32), ("ck", C.c_int32)]
+
+
+class PackBatch:
+    """Every PackedConv of a model (its forward, dgrad and column forms) re-packed from the fp32 parameters by ONE
+    launch (`tdvc_pack_conv_weights_batch`): after an optimizer step ~400 small packing launches and ~200 bias copies
+    become one kernel.  The job table lives on the device and is rebuilt when a tensor it points at has moved."""
+
+    def __init__(self, pcs):
+        self.pcs = []
+        seen = set()
+
+        def walk(pc):
+            if pc is None or id(pc) in seen:
+                return
+            seen.add(id(pc))
+            self.pcs.append(pc)
+            walk(pc.dgrad)
+            walk(pc.__dict__.get("_colpc"))
+        for pc in pcs:
+            walk(pc)
+        self._build()
+
+    def _tensors(self, pc):
+        tb = pc.tables
+        return [pc.wsrc, tb.row_off, tb.chan_off, tb.tap_off, tb.row_mask, tb.chan_mask, tb.tap_mask, pc.w] + \
+               ([pc.bsrc, pc.bias] if pc.bsrc is not None else [])
+
+    def _build(self):
+        lib = L.lib()
+        jobs = (_PackJob * len(self.pcs))()
+        starts = [0]
+        self._keep = []
+        self._ptrs = []
+        dev = self.pcs[0].w.device
+        for j, pc in zip(jobs, self.pcs):
+            tb = pc.tables
+            w = pc.wsrc.detach()
+            assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
+            j.w, j.row_off, j.chan_off, j.tap_off = w.data_ptr(), tb.row_off.data_ptr(), tb.chan_off.data_ptr(), tb.tap_off.data_ptr()
+            j.row_mask, j.chan_mask, j.tap_mask = tb.row_mask.data_ptr(), tb.chan_mask.data_ptr(), tb.tap_mask.data_ptr()
+            j.dst = pc.w.data_ptr()
+            j.cout, j.cin, j.ntaps, j.ck = tb.cout, tb.cin, len(tb.taps), tb.ck
+            if pc.bsrc is not None:
+                b = pc.bsrc.detach()
+                assert b.is_cuda and b.dtype == torch.float32 and b.is_contiguous() and pc.bias.dtype == torch.float32
+                j.bias_src, j.bias_dst = b.data_ptr(), pc.bias.data_ptr()
+                if pc.shuffle:
+                    perm = torch.from_numpy(convpack.shuffle_perm(pc.cout).astype(np.int32)).to(dev)
+                    self._keep.append(perm)
+                    j.bias_perm = perm.data_ptr()
+            nb = lib.tdvc_pack_job_blocks(tb.cout, tb.cin, len(tb.taps), tb.ck)
+            assert nb > 0
+            starts.append(starts[-1] + nb)
+            self._ptrs.append([t.data_ptr() for t in self._tensors(pc)])
+        self.total_blocks = starts[-1]
+        self.jobs = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
+        self.starts = torch.tensor(starts, dtype=torch.int32, device=dev)
+
+    def run(self):
+        for pc, ptrs in zip(self.pcs, self._ptrs):
+            if [t.data_ptr() for t in self._tensors(pc)] != ptrs:
+                self._build()
+                break
+        L.check(L.lib().tdvc_pack_conv_weights_batch(self.jobs.data_ptr(), self.starts.data_ptr(), len(self.pcs), self.total_blocks, _stream()),
+                "pack_conv_weights_batch")
+
+
 def _pick_ck(cin, cout, kh, kw, stride, pad):
     if (stride == 1 or (stride == 2 and kh == 1 and kw == 1 and pad == 0)) and cin >= 32 and cout >= 64:
         return 32            # the weight-stationary / pipelined kernels stream 32-channel chunks

@@ -24,13 +24,18 @@ from .synth import split_optim_params
 
 def refresh_packed(model: torch.nn.Module) -> None:
     """after an optimizer step: every packed layer follows its (in-place updated) parameters"""
+    pcs = []
     for m in model.modules():
         if hasattr(m, "refresh_packed"):
             m.refresh_packed()                       # GDN (effective gamma / beta), EntropyBottleneck (packed table)
             continue
-        for pc in m.__dict__.get("_packed", {}).values():
-            if isinstance(pc, ops.PackedConv):
-                pc.repack()
+        pcs += [pc for pc in m.__dict__.get("_packed", {}).values() if isinstance(pc, ops.PackedConv)]
+    batch = model.__dict__.get("_pack_batch")
+    if batch is None or [id(pc) for pc in batch.roots] != [id(pc) for pc in pcs]:
+        batch = ops.PackBatch(pcs)                   # one launch for every conv layer (forward, dgrad and column forms)
+        batch.roots = pcs
+        model.__dict__["_pack_batch"] = batch
+    batch.run()
 
 
 class GradBuckets:

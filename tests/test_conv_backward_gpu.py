@@ -92,6 +92,42 @@ def test_repack_follows_parameter_updates(report):
     assert not torch.allclose(y0, y1)
 
 
+def test_pack_batch_equals_per_layer_repack(report):
+    """the one-launch re-pack of many layers (forward + dgrad forms, biases incl. the sub-pixel row order) writes
+    exactly the bytes the per-layer repack() writes"""
+    ops = _ops()
+    geo = [(64, 64, 3, 1, 1, False), (128, 64, 3, 2, 1, False), (64, 128, 1, 1, 0, False), (256, 64, 3, 1, 1, True),
+           (32, 64, 7, 1, 3, False), (64, 8, 3, 1, 1, False)]
+    layers = []
+    for i, (co, ci, k, s_, pd, shuf) in enumerate(geo):
+        w = torch.nn.Parameter((randn(co, ci, k, k, seed=300 + i) * 0.05).cuda())
+        b = torch.nn.Parameter((randn(co, seed=320 + i) * 0.1).cuda())
+        pc = ops.pack_conv(w, b, stride=s_, pad=pd, shuffle=shuf)
+        g = to_fm(rnd16(randn(1, co, 32 // s_, 64 // s_, seed=340 + i)), ops)
+        layers.append((w, b, pc))
+        ops.conv_dgrad(pc, g, ops.FM.zeros(1, 32, 64, max(ci, 8)), accumulate=False)      # builds the dgrad form
+    batch = ops.PackBatch([pc for _, _, pc in layers])
+    assert len(batch.pcs) >= len(layers)
+    with torch.no_grad():
+        for w, b, _ in layers:
+            w.mul_(0.7).add_(0.01)
+            b.sub_(0.3)
+    for _, _, pc in layers:
+        pc.repack()
+    want = [(pc.w.clone(), None if pc.bias is None else pc.bias.clone()) for pc in batch.pcs]
+    for pc in batch.pcs:
+        pc.w.zero_()
+        if pc.bsrc is not None:
+            pc.bias.zero_()
+    batch.run()
+    torch.cuda.synchronize()
+    for pc, (w0, b0) in zip(batch.pcs, want):
+        assert torch.equal(pc.w, w0)
+        if pc.bsrc is not None:
+            assert torch.equal(pc.bias, b0)
+    report(f"pack batch: {len(batch.pcs)} packed forms in {batch.total_blocks} blocks, bytes identical to repack()")
+
+
 def test_act_backward_and_unshuffle(report):
     ops = _ops()
     y = rnd16(randn(2, 64, 9, 13, seed=121))
