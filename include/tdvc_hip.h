@@ -297,6 +297,12 @@ int64_t tdvc_conv_wgrad_work_floats(int cout, int cin, int ntaps, int N, int Ho,
 int tdvc_conv_wgrad(const tdvc_fmap* g, const tdvc_fmap* x, int cout, int kh, int kw, int stride, int pad,
                     int ntaps, const int8_t* tap_dy, const int8_t* tap_dx, const int32_t* row_off, const int32_t* chan_off,
                     const int32_t* tap_off, int square_x, float scale, float* dw, float* work, int64_t work_floats, void* stream);
+/* The same, and the bias gradient from the dY tiles the kernel already holds (saves a pass over dY):
+ * db[bias_index ? bias_index[co] : co] += scale * sum_{n,oy,ox} g[n,oy,ox,co], co < cout; db == NULL skips it. */
+int tdvc_conv_wgrad_bias(const tdvc_fmap* g, const tdvc_fmap* x, int cout, int kh, int kw, int stride, int pad,
+                         int ntaps, const int8_t* tap_dy, const int8_t* tap_dx, const int32_t* row_off, const int32_t* chan_off,
+                         const int32_t* tap_off, int square_x, float scale, float* dw, const int32_t* bias_index, float* db,
+                         float* work, int64_t work_floats, void* stream);
 
 /* out = g * act'(z), ReLU / LeakyReLU, the sign of z taken from the stored output (y - res); out may alias g. */
 int tdvc_act_backward(const tdvc_fmap* g, const tdvc_fmap* y, const tdvc_fmap* res, int act, float slope, const tdvc_fmap* out, void* stream);

@@ -78,6 +78,7 @@ SIGNATURES = {
     "tdvc_dcn_col2im": (_i, [_FM, _FM, _FM, _i, _P, _FM, _P]),
     "tdvc_conv_wgrad_work_floats": (_i64, [_i] * 6),
     "tdvc_conv_wgrad": (_i, [_FM, _FM] + [_i] * 6 + [_P] * 5 + [_i, _f, _P, _P, _i64, _P]),
+    "tdvc_conv_wgrad_bias": (_i, [_FM, _FM] + [_i] * 6 + [_P] * 5 + [_i, _f, _P, _P, _P, _P, _i64, _P]),
     "tdvc_gdn_backward": (_i, [_FM, _FM, _FM, _i, _FM, _FM, _P]),
     "tdvc_mul2_accumulate": (_i, [_FM, _FM, _FM, _P]),
     "tdvc_dcn_fused": (_i, [C.POINTER(DcnDesc), _P]),

@@ -122,9 +122,8 @@ def record_conv(tape: Tape, x: FM, pc, y, act, slope, res, res2, gdn, aux, squar
         gq = ops.pixel_unshuffle(g) if pc.shuffle else g
         if tape.needs_grad(x):
             ops.conv_dgrad(pc, gq, tape.grad(x), accumulate=True)
-        ops.conv_wgrad(pc, gq, x, param_grad(weight).view(-1), scale=tape.inv_scale)
-        if bias is not None:
-            ops.conv_bgrad(pc, gq, param_grad(bias), scale=tape.inv_scale)
+        ops.conv_wgrad(pc, gq, x, param_grad(weight).view(-1), scale=tape.inv_scale,
+                       db=param_grad(bias) if bias is not None else None)       # bias gradient from the same launch
 
     tape.add(bwd)
 
@@ -202,8 +201,7 @@ def record_dcn_fused(tape: Tape, x: FM, om: FM, pc, out: FM, groups, act, slope)
             g = ops.act_backward(g, out, act, slope)
         cpc = ops.dcn_column_conv(pc, groups)
         col = ops.dcn_columns(x, om, groups)
-        ops.conv_wgrad(cpc, g, col, param_grad(weight).view(-1), scale=tape.inv_scale)
-        ops.conv_bgrad(cpc, g, param_grad(bias), scale=tape.inv_scale)
+        ops.conv_wgrad(cpc, g, col, param_grad(weight).view(-1), scale=tape.inv_scale, db=param_grad(bias))
         dcol = ops.conv_dgrad(cpc, g, col, accumulate=False)            # overwrites the column buffer
         dx32 = ops.dcn_col2im(x, om, dcol, groups, tape.grad(om))
         if tape.needs_grad(x):
@@ -232,8 +230,7 @@ def record_gdn(tape: Tape, x: FM, pc, y: FM, res, gdn):
         ops.mul2_accumulate(dx, x, t)
         dgamma = torch.zeros_like(pc.wsrc)
         dbeta = torch.zeros_like(pc.bsrc)
-        ops.conv_wgrad(pc, dn, x, dgamma.view(-1), scale=tape.inv_scale, square_x=True)
-        ops.conv_bgrad(pc, dn, dbeta, scale=tape.inv_scale)
+        ops.conv_wgrad(pc, dn, x, dgamma.view(-1), scale=tape.inv_scale, square_x=True, db=dbeta)
         owner.accumulate_param_grads(dgamma.view(dgamma.shape[0], dgamma.shape[1]), dbeta)
 
     tape.add(bwd)

@@ -98,6 +98,7 @@ struct WgradParams {
   int tih, tiw;                                 // X tile extent in pixels
   int square_x;                                 // contract with x^2 (GDN norm pool: dgamma = sum dnorm * x^2)
   float* work;                                  // [P][ntaps_all][co_tiles*64][ci_tiles*32]
+  float* bwork;                                 // [P][co_tiles*64] column sums of dY (bias gradient), or null
 };
 
 typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
@@ -185,6 +186,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   }
   const unsigned char* abase = gt + (8 * khalf + rq) * PSG + colbase * 2;
   const unsigned char* bbase = xt + (8 * khalf + rq) * p.stride * PSX + colbase * 2;
+  // bias gradient rides along: the workgroups of input-channel tile 0 / tap group 0 also sum their dY tiles per channel
+  const bool do_bias = p.bwork != nullptr && cit == 0 && blockIdx.z == 0;
+  float bs[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) bs[q] = 0.f;
   if (worker < p.nblocks) prefetch(worker);
   for (int blk = worker; blk < p.nblocks; blk += nworkers) {
     __syncthreads();                                                // previous block's reads are done
@@ -192,6 +198,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     for (int j = 0; j < GL; ++j) {
       const int it = tid + j * 256;
       *reinterpret_cast<half8*>(gt + (it >> 3) * PSG + (it & 7) * 16) = gr[j];
+    }
+    if (do_bias) {                                                  // this thread's pieces all carry channels 8*(tid&7) ..
+#pragma unroll
+      for (int j = 0; j < GL; ++j)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bs[q] += (float)gr[j][q];
     }
 #pragma unroll
     for (int j = 0; j < XL; ++j) {
@@ -237,6 +249,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       }
     }
   }
+  if (do_bias) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);                    // [32 pixel lanes][64 channels]
+#pragma unroll
+    for (int q = 0; q < 8; ++q) red[(tid >> 3) * 64 + (tid & 7) * 8 + q] = bs[q];
+    __syncthreads();
+    if (tid < 64) {
+      float t = 0.f;
+      for (int r = 0; r < 32; ++r) t += red[r * 64 + tid];
+      p.bwork[(long)worker * p.co_tiles * WG_CO + co0 + tid] = t;
+    }
+  }
   // ---- partial dW block -> workspace[worker][co][ci][tap]
   const int CIW = p.ci_tiles * WG_CI, COW = p.co_tiles * WG_CO;
   float* wk = p.work + (long)worker * p.ntaps_all * COW * CIW;       // [worker][tap][co][ci]: a half wave stores 128 contiguous bytes
@@ -261,10 +285,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 // zero-padded channels and Conv3d holders scatter to the right parameter element
 __global__ void wgrad_reduce_kernel(const float* __restrict__ work, int nworkers, int COW, int CIW, int ntaps, const int* __restrict__ row_off,
                                     const int* __restrict__ chan_off, const int* __restrict__ tap_off, int cout, int cin, float scale,
-                                    float* __restrict__ dw) {
+                                    float* __restrict__ dw, int wblocks, const float* __restrict__ bwork,
+                                    const int* __restrict__ bias_index, float* __restrict__ db) {
   // 64 elements per workgroup, 4 worker slices per element (fixed order: the sum is reproducible)
   __shared__ float part[4][64];
   const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  if ((int)blockIdx.x >= wblocks) {                         // bias gradient: db[index[co]] += scale * sum_w bwork[w][co]
+    const int co = ((int)blockIdx.x - wblocks) * 64 + e;
+    float s = 0.f;
+    if (co < cout)
+      for (int w = sl; w < nworkers; w += 4) s += bwork[(long)w * COW + co];
+    part[sl][e] = s;
+    __syncthreads();
+    if (sl != 0 || co >= cout) return;
+    const int d = bias_index ? bias_index[co] : co;
+    if (d >= 0) db[d] += ((part[0][e] + part[1][e]) + (part[2][e] + part[3][e])) * scale;
+    return;
+  }
   const long i = (long)blockIdx.x * 64 + e;
   const long total = (long)cout * cin * ntaps;
   const bool live = i < total;
@@ -329,12 +366,13 @@ extern "C" int64_t tdvc_conv_wgrad_work_floats(int cout, int cin, int ntaps, int
   if (cout <= 0 || cin <= 0 || ntaps <= 0 || ntaps > TDVC_MAX_TAPS || N <= 0 || Ho <= 0 || Wo <= 0) return TDVC_EINVAL;
   const int co_tiles = (cout + WG_CO - 1) / WG_CO, ci_tiles = (cin + WG_CI - 1) / WG_CI, groups = (ntaps + WG_MAXT - 1) / WG_MAXT;
   const int nblocks = N * ((Ho + WG_TH - 1) / WG_TH) * ((Wo + WG_TW - 1) / WG_TW);
-  return (int64_t)wgrad_workers(co_tiles, ci_tiles, groups, nblocks, ntaps) * co_tiles * WG_CO * ci_tiles * WG_CI * ntaps;
+  return (int64_t)wgrad_workers(co_tiles, ci_tiles, groups, nblocks, ntaps) * co_tiles * WG_CO * (ci_tiles * WG_CI * ntaps + 1);   // + bias partials
 }
 
-extern "C" int tdvc_conv_wgrad(const tdvc_fmap* g, const tdvc_fmap* x, int cout, int kh, int kw, int stride, int pad,
-                               int ntaps, const int8_t* tap_dy, const int8_t* tap_dx, const int32_t* row_off, const int32_t* chan_off,
-                               const int32_t* tap_off, int square_x, float scale, float* dw, float* work, int64_t work_floats, void* stream) {
+extern "C" int tdvc_conv_wgrad_bias(const tdvc_fmap* g, const tdvc_fmap* x, int cout, int kh, int kw, int stride, int pad,
+                                    int ntaps, const int8_t* tap_dy, const int8_t* tap_dx, const int32_t* row_off, const int32_t* chan_off,
+                                    const int32_t* tap_off, int square_x, float scale, float* dw, const int32_t* bias_index, float* db,
+                                    float* work, int64_t work_floats, void* stream) {
   TDVC_CHECK(g && x && dw && work && tap_dy && tap_dx && row_off && chan_off && tap_off, "tdvc_conv_wgrad: null pointer");
   TDVC_CHECK(fmap_ok16(*g) && fmap_ok16(*x) && g->N == x->N, "tdvc_conv_wgrad: fmaps must be fp16 with matching batch");
   TDVC_CHECK(stride == 1 || stride == 2, "tdvc_conv_wgrad: stride %d", stride);
@@ -362,6 +400,7 @@ extern "C" int tdvc_conv_wgrad(const tdvc_fmap* g, const tdvc_fmap* x, int cout,
   p.square_x = square_x;
   const int groups = (ntaps + WG_MAXT - 1) / WG_MAXT;
   const int workers = wgrad_workers(p.co_tiles, p.ci_tiles, groups, p.nblocks, ntaps);
+  p.bwork = db ? work + (long)workers * p.co_tiles * WG_CO * p.ci_tiles * WG_CI * ntaps : nullptr;
   const int xl = (p.tih * p.tiw * (WG_CI / 8) + 255) / 256;
   TDVC_CHECK(xl <= 18, "tdvc_conv_wgrad: X tile of %dx%d pixels needs %d pieces per thread (max 18)", p.tih, p.tiw, xl);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -374,7 +413,15 @@ extern "C" int tdvc_conv_wgrad(const tdvc_fmap* g, const tdvc_fmap* x, int cout,
   const int rc = xl <= 6 ? go(&conv_wgrad_kernel<6>) : (xl <= 9 ? go(&conv_wgrad_kernel<9>) : go(&conv_wgrad_kernel<18>));
   if (rc) return rc;
   const long total = (long)cout * cin * ntaps;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, work, workers, p.co_tiles * WG_CO,
-                     p.ci_tiles * WG_CI, ntaps, row_off, chan_off, tap_off, cout, cin, scale, dw);
+  const int wblocks = (int)((total + 63) / 64), bblocks = db ? (cout + 63) / 64 : 0;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(wblocks + bblocks)), dim3(256), 0, st, work, workers, p.co_tiles * WG_CO,
+                     p.ci_tiles * WG_CI, ntaps, row_off, chan_off, tap_off, cout, cin, scale, dw, wblocks, p.bwork, bias_index, db);
   return tdvc_launch_status("tdvc_conv_wgrad");
+}
+
+extern "C" int tdvc_conv_wgrad(const tdvc_fmap* g, const tdvc_fmap* x, int cout, int kh, int kw, int stride, int pad,
+                               int ntaps, const int8_t* tap_dy, const int8_t* tap_dx, const int32_t* row_off, const int32_t* chan_off,
+                               const int32_t* tap_off, int square_x, float scale, float* dw, float* work, int64_t work_floats, void* stream) {
+  return tdvc_conv_wgrad_bias(g, x, cout, kh, kw, stride, pad, ntaps, tap_dy, tap_dx, row_off, chan_off, tap_off, square_x, scale, dw, nullptr, nullptr,
+                              work, work_floats, stream);
 }

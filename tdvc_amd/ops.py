@@ -426,8 +426,9 @@ def conv_dgrad(pc: PackedConv, g: FM, dx: FM, accumulate=True) -> FM:
     return conv(g, dpc, out=dx, res=dx if accumulate else None)
 
 
-def conv_wgrad(pc: PackedConv, g: FM, x: FM, dw: torch.Tensor, scale=1.0, square_x=False) -> None:
-    """dW += scale * dL/dW (fp32, the parameter's own layout); `g` as in conv_dgrad.  `pc.orig["wgrad_taps"]` widens
+def conv_wgrad(pc: PackedConv, g: FM, x: FM, dw: torch.Tensor, scale=1.0, square_x=False, db: torch.Tensor | None = None) -> None:
+    """dW += scale * dL/dW (fp32, the parameter's own layout); `g` as in conv_dgrad.  With `db` the bias gradient
+    (what `conv_bgrad` computes) comes out of the same launch: the kernel already holds the dY tiles.  `pc.orig["wgrad_taps"]` widens
     the tap list beyond the forward's (masked convs: the reference's autograd also fills the masked taps)."""
     o = pc.orig
     taps = o.get("wgrad_taps") or o["taps"]
@@ -447,8 +448,13 @@ def conv_wgrad(pc: PackedConv, g: FM, x: FM, dw: torch.Tensor, scale=1.0, square
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    L.check(lib.tdvc_conv_wgrad(C.byref(dg), C.byref(dxd), pc.cout, o["kh"], o["kw"], o["stride"], o["pad"], len(taps), dy, dxs,
+    bidx = None
+    if db is not None:
+        assert db.is_cuda and db.dtype == torch.float32 and db.is_contiguous() and db.numel() >= pc.cout
+        bidx = _bias_index(pc, db.device)
+    L.check(lib.tdvc_conv_wgrad_bias(C.byref(dg), C.byref(dxd), pc.cout, o["kh"], o["kw"], o["stride"], o["pad"], len(taps), dy, dxs,
                                 tb.row_off.data_ptr(), tb.chan_off.data_ptr(), tb.tap_off.data_ptr(), int(square_x), scale, dw.data_ptr(),
+                                bidx.data_ptr() if bidx is not None else None, db.data_ptr() if db is not None else None,
                                 work.data_ptr(), nwork, _stream()), "conv_wgrad")
     if PROFILE is not None:
         e1.record()
@@ -457,13 +463,18 @@ def conv_wgrad(pc: PackedConv, g: FM, x: FM, dw: torch.Tensor, scale=1.0, square
                             bytes=0.0))
 
 
+def _bias_index(pc: PackedConv, device):
+    idx = pc.__dict__.get("_bg_index")
+    if idx is None and pc.shuffle:
+        idx = torch.from_numpy(convpack.shuffle_perm(pc.cout)).to(torch.int32).to(device)
+        pc.__dict__["_bg_index"] = idx
+    return idx
+
+
 def conv_bgrad(pc: PackedConv, g: FM, db: torch.Tensor, scale=1.0) -> None:
     """db += scale * sum over batch and pixels of g (rows un-permuted for sub-pixel layers)"""
     lib = L.lib()
-    idx = pc.__dict__.get("_bg_index")
-    if idx is None and pc.shuffle:
-        idx = torch.from_numpy(convpack.shuffle_perm(pc.cout)).to(torch.int32).to(db.device)
-        pc.__dict__["_bg_index"] = idx
+    idx = _bias_index(pc, db.device)
     nwork = lib.tdvc_bias_grad_work_floats(g.N, g.C)
     work = torch.empty((nwork,), dtype=torch.float32, device=db.device)
     dg = g.desc()

@@ -63,10 +63,15 @@ def test_conv_backward(case, report):
     tol_w = 2e-3 * float(gw.abs().max()) + 1e-3
     assert_close(dw.cpu() - 0.25, gw, 2e-3, tol_w, f"wgrad {name}", report)
     assert_close(db.cpu() + 0.5, gb, 2e-3, 2e-3 * float(gb.abs().max()) + 1e-3, f"bgrad {name}", report)
-    # bitwise reproducible
+    # bitwise reproducible; the fused form (bias gradient from the same launch) gives the same dW and a matching db
     dw2 = torch.full_like(wd, 0.25)
-    ops.conv_wgrad(pc, gq, xf, dw2)
+    db2 = torch.full_like(bd, -0.5)
+    ops.conv_wgrad(pc, gq, xf, dw2, db=db2)
     assert torch.equal(dw, dw2)
+    assert_close(db2.cpu() + 0.5, gb, 2e-3, 2e-3 * float(gb.abs().max()) + 1e-3, f"fused bgrad {name}", report)
+    db3 = torch.full_like(bd, -0.5)
+    ops.conv_wgrad(pc, gq, xf, torch.zeros_like(wd), db=db3)
+    assert torch.equal(db2, db3)
 
 
 def test_repack_follows_parameter_updates(report):
