@@ -173,7 +173,9 @@ def train_leg(a, rank, world, dev, dist):
         xs.append(g[3:4])
         rs.append(ref_list([g[0:1], g[1:2], g[2:3]]))
     x, refs = torch.cat(xs), torch.cat(rs)
-    step = TrainStep(m, train_lambda=2048.0, lr=1e-4, loss_scale=128.0)
+    step = TrainStep(m, train_lambda=2048.0, lr=1e-4, loss_scale=128.0, graph=a.graph)
+    for _ in range(2 if a.graph else 0):                 # eager steps that precede the capture (not part of --warmup)
+        step(x, refs)
     for _ in range(a.warmup):
         log = step(x, refs)
     torch.cuda.synchronize()
@@ -215,6 +217,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=("infer", "train"), default="infer",
                     help="infer (default, the headline metric) | train: BASELINE.json configs[2]/[3], one optimisation step per step")
+    ap.add_argument("--graph", action="store_true", help="--mode train: replay the forward + backward as one captured HIP graph")
     ap.add_argument("--train-batch", type=int, default=4, help="samples per rank in --mode train (256x256 P-frames)")
     a = ap.parse_args()
 

@@ -80,8 +80,13 @@ class GradBuckets:
 
 class TrainStep:
     def __init__(self, model, train_lambda: float = 2048.0, lr: float = 1e-4, loss_scale: float = 1024.0, clip: float = 2.0,
-                 dynamic_scale: bool = True, growth_interval: int = 2000):
+                 dynamic_scale: bool = True, growth_interval: int = 2000, graph: bool = False, graph_warmup: int = 2):
+        """graph=True: after `graph_warmup` eager steps (they build every lazily packed form) the forward + backward of
+        one step is captured into a HIP graph and replayed: ~2300 launches leave the Python interpreter's critical
+        path.  Input shapes are then fixed; a loss-scale change re-captures."""
         self.model = model
+        self.use_graph, self.graph_warmup, self._eager_steps = bool(graph), int(graph_warmup), 0
+        self._graph = None
         self.lam = float(train_lambda)
         self.loss_scale = float(loss_scale)
         self.clip = float(clip)
@@ -96,21 +101,47 @@ class TrainStep:
         self.optimizer = torch.optim.Adam(self.main_params, lr=lr)
         self.aux_optimizer = torch.optim.Adam(self.aux_params, lr=10 * lr)          # utils.py:110-112
 
-    def __call__(self, input_image: torch.Tensor, refer_frames: torch.Tensor) -> dict:
-        model = self.model
-        model.train()
+    def _forward_backward(self, input_image, refer_frames):
+        """forward, loss seeds, backward: gradients accumulate into the (zeroed) buckets"""
         B, _, H, W = input_image.shape
         self.buckets.zero()
-        for p in self.aux_params:
-            p.grad = None
         with autograd.record(self.loss_scale) as tape:
-            recon, bpp_res, bpp_mv, aux_mv, aux_res = model(input_image, refer_frames, True)
+            recon, bpp_res, bpp_mv, _, _ = self.model(input_image, refer_frames, True)
             diff = recon - input_image.float()
-            mse = (diff * diff).mean()
             # d(lambda * MSE)/d recon, scaled; the rate terms are seeded through tape.rate_grad
             tape.grad_tensor(recon).copy_(diff * (2.0 * self.lam * self.loss_scale / diff.numel()))
             tape.rate_grad = 1.0 / float(B * H * W)
             tape.backward()
+        # MSE itself is reduced by the caller, outside a captured graph: torch's multi-block reduction zeroes its
+        # semaphores with a memset node, and on this ROCm build the first replay after other work on the stream returned
+        # partial sums (tools/dbg_graph6.py); the gradients never depended on that scalar
+        return diff, bpp_res.mean(), bpp_mv.mean()
+
+    def _capture(self, input_image, refer_frames):
+        self._static_in = (input_image.clone(), refer_frames.clone())
+        self._graph = torch.cuda.CUDAGraph()
+        self._graph_scale = self.loss_scale
+        torch.cuda.synchronize()
+        with torch.cuda.graph(self._graph):
+            self._static_out = self._forward_backward(*self._static_in)
+
+    def __call__(self, input_image: torch.Tensor, refer_frames: torch.Tensor) -> dict:
+        model = self.model
+        model.train()
+        for p in self.aux_params:
+            p.grad = None
+        if self.use_graph and self._eager_steps >= self.graph_warmup:
+            if (self._graph is None or self._graph_scale != self.loss_scale or self._static_in[0].shape != input_image.shape
+                    or self._static_in[1].shape != refer_frames.shape):
+                self._capture(input_image, refer_frames)
+            self._static_in[0].copy_(input_image)
+            self._static_in[1].copy_(refer_frames)
+            self._graph.replay()
+            diff, bpp_res, bpp_mv = self._static_out
+        else:
+            diff, bpp_res, bpp_mv = self._forward_backward(input_image, refer_frames)
+            self._eager_steps += 1
+        mse = (diff * diff).mean()
         self.buckets.all_reduce_mean()
         finite = all(bool(torch.isfinite(b).all()) for b in self.buckets.buckets)      # after the mean: every rank agrees
         if finite:
@@ -124,10 +155,10 @@ class TrainStep:
             if self.dynamic_scale:
                 self.loss_scale *= 0.5
                 self._clean_steps = 0
-        aux = aux_mv + aux_res
+        aux = model.mvCoder.aux_loss() + model.resCoder.aux_loss()      # pnet.py's forward returns exactly these two
         aux.backward()
         self.aux_optimizer.step()
         refresh_packed(model)
-        return dict(rd_loss=float(self.lam * mse + bpp_res.mean() + bpp_mv.mean()), mse=float(mse), bpp_res=float(bpp_res.mean()),
-                    bpp_mv=float(bpp_mv.mean()), aux_loss=float(aux.detach()), grad_norm=float(gnorm), loss_scale=self.loss_scale,
+        return dict(rd_loss=float(self.lam * mse + bpp_res + bpp_mv), mse=float(mse), bpp_res=float(bpp_res),
+                    bpp_mv=float(bpp_mv), aux_loss=float(aux.detach()), grad_norm=float(gnorm), loss_scale=self.loss_scale,
                     skipped=not finite)

@@ -424,3 +424,30 @@ def test_full_model_backward_and_steps(report):
     report("full model train steps: " + "; ".join(f"rd {l['rd_loss']:.4f} |g| {l['grad_norm']:.3e}" for l in logs))
     assert all(l["rd_loss"] == l["rd_loss"] and l["grad_norm"] == l["grad_norm"] for l in logs)
     assert logs[-1]["rd_loss"] < logs[0]["rd_loss"]
+
+
+def test_train_step_graph_replay_matches_eager(report):
+    """TrainStep(graph=True) replays the captured forward + backward: same trajectory as the eager step on the same sample
+    (the noise draws differ, so to a tolerance), the gradient buckets re-zeroed inside the graph, MSE reduced outside it"""
+    from tdvc_amd import synth
+    from tdvc_amd.model.pnet import VideoCompressor
+    from tdvc_amd.train import TrainStep
+    H = W = 128
+    gop = synth.make_gop(4321, 7, H, W).float()
+    x = gop[3:4].cuda()
+    refs = torch.stack([gop[0], gop[0], gop[1], gop[2]]).unsqueeze(0).cuda()
+    logs = {}
+    for mode in (False, True):
+        torch.manual_seed(5)
+        m = VideoCompressor()
+        synth.fill_parameters(m)
+        m = m.cuda()
+        step = TrainStep(m, train_lambda=2048.0, lr=1e-4, loss_scale=128.0, graph=mode, graph_warmup=2)
+        logs[mode] = [step(x, refs) for _ in range(7)]
+        assert (step._graph is not None) == mode
+    for i, (a, b) in enumerate(zip(logs[False], logs[True])):
+        assert not b["skipped"] and 0.0 < b["mse"] < 1.0
+        assert abs(a["rd_loss"] - b["rd_loss"]) <= 0.05 * abs(a["rd_loss"]), (i, a["rd_loss"], b["rd_loss"])
+        assert abs(a["bpp_res"] - b["bpp_res"]) <= 0.02 * a["bpp_res"] and abs(a["bpp_mv"] - b["bpp_mv"]) <= 0.05 * a["bpp_mv"]
+    report("train step, eager vs graph replay: " + "; ".join(f"{a['rd_loss']:.3f}/{b['rd_loss']:.3f}" for a, b in zip(logs[False], logs[True])))
+    assert logs[True][-1]["rd_loss"] < logs[True][0]["rd_loss"]

@@ -1,0 +1,20 @@
+"""Per-kernel totals of the LAST training step in a rocprofv3 kernel trace (steps are delimited by pack_batch_kernel)."""
+import collections
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+marks = [i for i, r in enumerate(rows) if "pack_batch_kernel" in r["Kernel_Name"]]
+a, b = marks[-2] + 1, marks[-1] + 1
+step = rows[a:b]
+tot = collections.Counter()
+cnt = collections.Counter()
+for r in step:
+    n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("at::native::", "")[:90]
+    tot[n] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    cnt[n] += 1
+wall = int(step[-1]["End_Timestamp"]) - int(step[0]["Start_Timestamp"])
+print(f"last step: {len(step)} kernels, busy {sum(tot.values()) / 1e6:.2f} ms, span {wall / 1e6:.2f} ms")
+for n, t in tot.most_common(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
+    print(f"{t / 1e6:8.3f} ms  n={cnt[n]:4d}  avg={t / cnt[n] / 1e3:8.1f} us  {n}")
