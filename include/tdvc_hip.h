@@ -364,12 +364,17 @@ int tdvc_eb_backward(const tdvc_fmap* z, const float* params, const tdvc_fmap* n
 int tdvc_gc_backward(const tdvc_fmap* y, const tdvc_fmap* gp, const tdvc_fmap* noise, float gscale, const tdvc_fmap* dy, const tdvc_fmap* dgp, void* stream);
 
 /* fp16 channel-innermost pieces of the fused DCN's backward (dcn_v2_cuda.cu:97-216 restructured): column channel
- * k = tap*8G + group*8 + j.  tdvc_dcn_columns: col = mask * bilinear samples (operand of dW = dY col^T, a 1x1
+ * k = group*72 + tap*8 + j.  tdvc_dcn_columns: col = mask * bilinear samples (operand of dW = dY col^T, a 1x1
  * tdvc_conv_wgrad).  tdvc_dcn_col2im: from dcol = W^T dY (a 1x1 tdvc_conv2d): offset / mask gradients accumulate
  * into dom (fp16, the offset-mask conv's output gradient, mask through its sigmoid), the bilinear scatter into
- * dx32 (fp32 [N][H][W][8G], zero-initialised by the caller; float atomics like the reference's col2im). */
+ * dx32 (fp32 [N][H][W][8G], zero-initialised by the caller).  The scatter is privatised: one 32x32-pixel LDS window
+ * per 16x16 tile and group, stored to `work` (tdvc_dcn_col2im_work_floats floats, 16-byte aligned) and summed per
+ * pixel in a fixed order; only samples displaced by more than 8 pixels use float atomics (the reference's col2im
+ * uses them for every sample). */
 int tdvc_dcn_columns(const tdvc_fmap* x, const tdvc_fmap* om, int groups, const tdvc_fmap* col, void* stream);
-int tdvc_dcn_col2im(const tdvc_fmap* x, const tdvc_fmap* om, const tdvc_fmap* dcol, int groups, float* dx32, const tdvc_fmap* dom, void* stream);
+int64_t tdvc_dcn_col2im_work_floats(int N, int H, int W, int groups);
+int tdvc_dcn_col2im(const tdvc_fmap* x, const tdvc_fmap* om, const tdvc_fmap* dcol, int groups, float* dx32, const tdvc_fmap* dom,
+                    float* work, int64_t work_floats, void* stream);
 
 #ifdef __cplusplus
 }

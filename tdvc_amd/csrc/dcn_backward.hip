@@ -151,8 +151,8 @@ __global__ __launch_bounds__(256) void bgrad_kernel(const float* __restrict__ gy
 }
 
 // ---------------------------------------------------------------------------------------------------
-// fp16 channel-innermost backward of the fused DCN (training path).  Column channel order k = t * 8G + g * 8 + j
-// (tap-major, 8 channels per deformable group), the order the fused forward stages its samples in.
+// fp16 channel-innermost backward of the fused DCN (training path).  Column channel order k = g * 72 + t * 8 + j
+// (group-major: the 9 taps x 8 channels one (pixel, group) thread reads are 144 contiguous bytes).
 //   dcn_columns_kernel : col[p][k] = mask(g,t,p) * bilinear(x[.., g*8+j], p + tap t + offset(g,t,p))      (for dW)
 //   dcn_col2im_kernel  : from dcol[p][k] = sum_co W[co][k] dY[p][co]:  d offset, d mask (raw, through the sigmoid) into
 //                        dom, and the bilinear scatter of dcol * mask into dx32 (float atomics: summation order is not
@@ -162,6 +162,7 @@ struct DcnBw {
   FMap x, om, col;           // col doubles as dcol
   FMap dom;
   float* dx32;
+  float* wbuf;               // [N*G][tiles][32*32*8] scatter windows
   int G;
 };
 
@@ -208,80 +209,159 @@ __global__ void dcn_columns_kernel(const DcnBw p, long total) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (half_t)(acc[j] * mask);
   }
-  *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.col.p) + (long)n * p.col.sn + pix * p.col.sp + t * 8 * p.G + g * 8) = o;
+  *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.col.p) + (long)n * p.col.sn + pix * p.col.sp + g * 72 + t * 8) = o;
 }
 
-// One workgroup = a 16x16 pixel tile of one (image, deformable group); the scatter goes to an LDS window of 32x32
-// pixels x 8 channels around the tile (ds_add_f32), samples that land outside it (offsets beyond +-8 pixels) go
-// straight to global memory; the window is then flushed with one global float atomic per non-zero element: ~9x
-// fewer global atomics than one per corner, and almost uncontended.
-constexpr int C2I_T = 16, C2I_R = 8, C2I_W = C2I_T + 2 * C2I_R;
-__global__ __launch_bounds__(256) void dcn_col2im_kernel(const DcnBw p) {
-  __shared__ float win[C2I_W * C2I_W * 8];
+// One single-wave workgroup = an 8x8 pixel tile of one (image, deformable group).  The bilinear scatter goes to an LDS
+// window of 24x24 pixels x 8 fp32 channels around the tile; samples displaced by more than 8 pixels fall back to global
+// float atomics.  LDS float atomics run at ~0.5 lane-adds per clock per CU on this part (604 M adds = 2.4 of the first
+// version's 3.1 ms), so they are the exception here: per (tap, corner) every lane stamps a tag at its target pixel and
+// reads it back; the lane whose stamp survived owns the pixel for this instruction and updates its 8 channels with
+// plain 128-bit LDS reads / writes, the (rare: the offset field is locally smooth) lanes that lost the stamp follow
+// with ds_add_f32.  One wave per workgroup, so LDS operations retire in program order and nobody else touches the
+// window.  The window is stored whole to the workgroup's slot of `wbuf` and dcn_window_gather_kernel adds the nine
+// windows that cover each pixel into dx32 in a fixed order.
+constexpr int C2I_T = 8, C2I_R = 8, C2I_W = C2I_T + 2 * C2I_R;
+__global__ __launch_bounds__(64) void dcn_col2im_kernel(const DcnBw p) {
+  __shared__ __attribute__((aligned(16))) float win[C2I_W * C2I_W * 8];
+  __shared__ half8 xw[C2I_W * C2I_W];                                // this group's 8 channels of x over the window (0 outside the image)
+  __shared__ int tag[C2I_W * C2I_W];
   const int H = p.x.H, W = p.x.W;
   const int tiles_x = (W + C2I_T - 1) / C2I_T;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
   const int g = blockIdx.y % p.G, n = blockIdx.y / p.G;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < C2I_W * C2I_W * 8; i += 256) win[i] = 0.f;
-  __syncthreads();
-  const int y = ty * C2I_T + (tid >> 4), xx = tx * C2I_T + (tid & 15);
+  const int lane = threadIdx.x;
   const int wy0 = ty * C2I_T - C2I_R, wx0 = tx * C2I_T - C2I_R;
   const half_t* xg = reinterpret_cast<const half_t*>(p.x.p) + (long)n * p.x.sn + g * 8;
   float* dxn = p.dx32 + ((long)n * H * W) * (8 * p.G) + g * 8;
-  if (y < H && xx < W) {
-    const long pix = (long)y * W + xx;
-    const half_t* omp = reinterpret_cast<const half_t*>(p.om.p) + (long)n * p.om.sn + pix * p.om.sp;
-    half_t* dop = reinterpret_cast<half_t*>(p.dom.p) + (long)n * p.dom.sn + pix * p.dom.sp;
-    const half_t* dcp = reinterpret_cast<const half_t*>(p.col.p) + (long)n * p.col.sn + pix * p.col.sp + g * 8;
+  for (int i = lane; i < C2I_W * C2I_W; i += 64) {
+    const int yy = wy0 + i / C2I_W, xc = wx0 + i % C2I_W;
+    half8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
+    if (yy >= 0 && yy < H && xc >= 0 && xc < W) v = *reinterpret_cast<const half8*>(xg + ((long)yy * W + xc) * p.x.sp);
+    xw[i] = v;
+    tag[i] = -1;
+  }
+  for (int i = lane; i < C2I_W * C2I_W * 2; i += 64) reinterpret_cast<float4*>(win)[i] = float4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  volatile __attribute__((address_space(3))) int* vtag = (volatile __attribute__((address_space(3))) int*)tag;      // ds_ ops, never forwarded
+  const int y = ty * C2I_T + (lane >> 3), xx = tx * C2I_T + (lane & 7);
+  const bool valid = y < H && xx < W;
+  const long pix = valid ? (long)y * W + xx : 0;
+  const half_t* omp = reinterpret_cast<const half_t*>(p.om.p) + (long)n * p.om.sn + pix * p.om.sp;
+  half_t* dop = reinterpret_cast<half_t*>(p.dom.p) + (long)n * p.dom.sn + pix * p.dom.sp;
+  const half_t* dcp = reinterpret_cast<const half_t*>(p.col.p) + (long)n * p.col.sn + pix * p.col.sp + g * 72;
+  half2v off[9];
+  float mk[9];
+  half8 dc8[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    off[t] = *reinterpret_cast<const half2v*>(omp + g * 18 + 2 * t);
+    mk[t] = __builtin_amdgcn_rcpf(1.f + __expf(-(float)omp[18 * p.G + g * 9 + t]));
+    dc8[t] = *reinterpret_cast<const half8*>(dcp + t * 8);
+  }
+  float dof[18], dmk[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float mask = mk[t];
+    const float h_im = (float)(y - 1 + t / 3) + (float)off[t][0], w_im = (float)(xx - 1 + t % 3) + (float)off[t][1];
+    const bool inside = valid && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+    float dc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dc[j] = (float)dc8[t][j];
+    const int hl = (int)floorf(h_im), wl = (int)floorf(w_im), hh = hl + 1, wh = wl + 1;
+    const float lh = h_im - hl, lw = w_im - wl;
+    float dval = 0.f, dh = 0.f, dw = 0.f;                     // sum_c dcol_c * {val_c, dval_c/dh, dval_c/dw}
+    auto corner = [&](int ci, int yy, int xc, float wt, float wth, float wtw) {
+      const bool active = inside && yy >= 0 && yy <= H - 1 && xc >= 0 && xc <= W - 1;
+      const int ly = yy - wy0, lx = xc - wx0;
+      const bool inwin = active && ly >= 0 && ly < C2I_W && lx >= 0 && lx < C2I_W;
+      const int tgt = inwin ? ly * C2I_W + lx : 0;
+      const long off_px = active ? ((long)yy * W + xc) : 0;
+      half8 v = xw[tgt];
+      if (active && !inwin) v = *reinterpret_cast<const half8*>(xg + off_px * p.x.sp);
+      float a[8], sx = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sx += dc[j] * (float)v[j];
+        a[j] = dc[j] * mask * wt;
+      }
+      if (active) { dval += wt * sx; dh += wth * sx; dw += wtw * sx; }
+      const int uid = ((t * 4 + ci) << 6) | lane;
+      if (inwin) vtag[tgt] = uid;
+      const bool owner = inwin && vtag[tgt] == uid;
+      if (owner) {
+        float4* w4 = reinterpret_cast<float4*>(win + tgt * 8);
+        float4 lo = w4[0], hi = w4[1];
+        lo.x += a[0]; lo.y += a[1]; lo.z += a[2]; lo.w += a[3];
+        hi.x += a[4]; hi.y += a[5]; hi.z += a[6]; hi.w += a[7];
+        w4[0] = lo; w4[1] = hi;
+      }
+      asm volatile("" ::: "memory");                         // the owners' stores are issued before the others' atomics
+      if (inwin && !owner) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(win + tgt * 8 + j, a[j]);
+      }
+      asm volatile("" ::: "memory");
+      if (active && !inwin) {
+        float* dg = dxn + off_px * (8 * p.G);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) unsafeAtomicAdd(dg + j, a[j]);
+      }
+    };
+    corner(0, hl, wl, (1.f - lh) * (1.f - lw), -(1.f - lw), -(1.f - lh));
+    corner(1, hl, wh, (1.f - lh) * lw, -lw, (1.f - lh));
+    corner(2, hh, wl, lh * (1.f - lw), (1.f - lw), -lh);
+    corner(3, hh, wh, lh * lw, lw, lh);
+    dof[2 * t] = dh * mask; dof[2 * t + 1] = dw * mask; dmk[t] = dval * mask * (1.f - mask);
+  }
+  if (valid) {
+#pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const float oh = (float)omp[g * 18 + 2 * t], ow = (float)omp[g * 18 + 2 * t + 1];
-      const float mask = 1.f / (1.f + __expf(-(float)omp[18 * p.G + g * 9 + t]));
-      const float h_im = (float)(y - 1 + t / 3) + oh, w_im = (float)(xx - 1 + t % 3) + ow;
-      if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) continue;
-      const half8 dc8 = *reinterpret_cast<const half8*>(dcp + t * 8 * p.G);
-      float dc[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) dc[j] = (float)dc8[j];
-      const int hl = (int)floorf(h_im), wl = (int)floorf(w_im), hh = hl + 1, wh = wl + 1;
-      const float lh = h_im - hl, lw = w_im - wl;
-      float dval = 0.f, dh = 0.f, dw = 0.f;                   // sum_c dcol_c * {val_c, dval_c/dh, dval_c/dw}
-      auto corner = [&](int yy, int xc, float wt, float wth, float wtw) {
-        if (yy < 0 || yy > H - 1 || xc < 0 || xc > W - 1) return;
-        const long off = ((long)yy * W + xc);
-        const half8 v = *reinterpret_cast<const half8*>(xg + off * p.x.sp);
-        const int ly = yy - wy0, lx = xc - wx0;
-        const bool inwin = ly >= 0 && ly < C2I_W && lx >= 0 && lx < C2I_W;
-        float* dl = win + (ly * C2I_W + lx) * 8;
-        float* dg = dxn + off * (8 * p.G);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float xv = (float)v[j];
-          dval += dc[j] * wt * xv;
-          dh += dc[j] * wth * xv;
-          dw += dc[j] * wtw * xv;
-          const float a = dc[j] * mask * wt;
-          if (inwin) atomicAdd(dl + j, a);
-          else unsafeAtomicAdd(dg + j, a);
-        }
-      };
-      corner(hl, wl, (1.f - lh) * (1.f - lw), -(1.f - lw), -(1.f - lh));
-      corner(hl, wh, (1.f - lh) * lw, -lw, (1.f - lh));
-      corner(hh, wl, lh * (1.f - lw), (1.f - lw), -lh);
-      corner(hh, wh, lh * lw, lw, lh);
-      dop[g * 18 + 2 * t] = (half_t)((float)dop[g * 18 + 2 * t] + dh * mask);
-      dop[g * 18 + 2 * t + 1] = (half_t)((float)dop[g * 18 + 2 * t + 1] + dw * mask);
-      dop[18 * p.G + g * 9 + t] = (half_t)((float)dop[18 * p.G + g * 9 + t] + dval * mask * (1.f - mask));
+      half2v* d2 = reinterpret_cast<half2v*>(dop + g * 18 + 2 * t);
+      const half2v o = *d2;
+      *d2 = half2v{(half_t)((float)o[0] + dof[2 * t]), (half_t)((float)o[1] + dof[2 * t + 1])};
+      half_t* dm = dop + 18 * p.G + g * 9 + t;
+      *dm = (half_t)((float)*dm + dmk[t]);
     }
   }
   __syncthreads();
-  for (int i = tid; i < C2I_W * C2I_W * 8; i += 256) {
-    const float v = win[i];
-    if (v == 0.f) continue;
-    const int j = i & 7, q = i >> 3;
-    const int yy = wy0 + q / C2I_W, xc = wx0 + q % C2I_W;
-    if (yy >= 0 && yy < H && xc >= 0 && xc < W) unsafeAtomicAdd(dxn + ((long)yy * W + xc) * (8 * p.G) + j, v);
-  }
+  float4* wb = reinterpret_cast<float4*>(p.wbuf + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (C2I_W * C2I_W * 8));
+  for (int i = lane; i < C2I_W * C2I_W * 2; i += 64) wb[i] = reinterpret_cast<const float4*>(win)[i];
+}
+
+// dx32[n][y][x][g*8 ..] += the (up to) nine windows that cover pixel (y, x): the tiles (ty - 1 .. ty + 1, tx - 1 .. tx + 1).
+// One thread per (n, g, y, x); fixed order, no atomics.
+__global__ void dcn_window_gather_kernel(const DcnBw p, int tiles_x, int tiles_y) {
+  const int H = p.x.H, W = p.x.W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)p.x.N * p.G * H * W) return;
+  const int g = (int)(i % p.G);
+  long q = i / p.G;
+  const int xx = (int)(q % W);
+  q /= W;
+  const int y = (int)(q % H), n = (int)(q / H);
+  const int ty = y / C2I_T, tx = xx / C2I_T;
+  float4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int wy = ty + dy, wx = tx + dx;
+      if (wy < 0 || wy >= tiles_y || wx < 0 || wx >= tiles_x) continue;
+      const int ly = y - (wy * C2I_T - C2I_R), lx = xx - (wx * C2I_T - C2I_R);
+      const float4* w = reinterpret_cast<const float4*>(p.wbuf + ((long)(n * p.G + g) * (tiles_x * tiles_y) + wy * tiles_x + wx) * (C2I_W * C2I_W * 8) +
+                                                        (ly * C2I_W + lx) * 8);
+      const float4 u = w[0], v = w[1];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+      b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+    }
+  float4* d = reinterpret_cast<float4*>(p.dx32 + (((long)n * H + y) * W + xx) * (8 * p.G) + g * 8);
+  float4 u = d[0], v = d[1];
+  u.x += a.x; u.y += a.y; u.z += a.z; u.w += a.w;
+  v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+  d[0] = u; d[1] = v;
 }
 
 inline dim3 g1(long n) { return dim3((unsigned)((n + 255) / 256)); }
@@ -339,18 +419,30 @@ static inline bool dcn_bw_ok(const tdvc_fmap& x, const tdvc_fmap& om, const tdvc
 extern "C" int tdvc_dcn_columns(const tdvc_fmap* x, const tdvc_fmap* om, int groups, const tdvc_fmap* col, void* stream) {
   TDVC_CHECK(x && om && col && dcn_bw_ok(*x, *om, *col, groups), "tdvc_dcn_columns: bad arguments (x C = 8*groups, om C >= 27*groups, col C = 72*groups)");
   DcnBw p;
+  p.wbuf = nullptr;
   p.x = to_dev(*x); p.om = to_dev(*om); p.col = to_dev(*col); p.dom = null_fmap(); p.dx32 = nullptr; p.G = groups;
   const long total = (long)x->N * x->H * x->W * groups * 9;
   hipLaunchKernelGGL(dcn_columns_kernel, g1(total), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, total);
   return tdvc_launch_status("tdvc_dcn_columns");
 }
 
-extern "C" int tdvc_dcn_col2im(const tdvc_fmap* x, const tdvc_fmap* om, const tdvc_fmap* dcol, int groups, float* dx32, const tdvc_fmap* dom, void* stream) {
-  TDVC_CHECK(x && om && dcol && dx32 && dom && dcn_bw_ok(*x, *om, *dcol, groups) && fmap_ok16(*dom) && dom->C >= 27 * groups && dom->N == x->N &&
+extern "C" int64_t tdvc_dcn_col2im_work_floats(int N, int H, int W, int groups) {
+  if (N <= 0 || H <= 0 || W <= 0 || groups <= 0) return TDVC_EINVAL;
+  return (int64_t)N * groups * ((W + C2I_T - 1) / C2I_T) * ((H + C2I_T - 1) / C2I_T) * (C2I_W * C2I_W * 8);
+}
+
+extern "C" int tdvc_dcn_col2im(const tdvc_fmap* x, const tdvc_fmap* om, const tdvc_fmap* dcol, int groups, float* dx32, const tdvc_fmap* dom,
+                               float* work, int64_t work_floats, void* stream) {
+  TDVC_CHECK(x && om && dcol && dx32 && dom && work && dcn_bw_ok(*x, *om, *dcol, groups) && fmap_ok16(*dom) && dom->C >= 27 * groups && dom->N == x->N &&
                  dom->H == x->H && dom->W == x->W, "tdvc_dcn_col2im: bad arguments");
+  TDVC_CHECK(work_floats >= tdvc_dcn_col2im_work_floats(x->N, x->H, x->W, groups) && (reinterpret_cast<uintptr_t>(work) & 15) == 0 &&
+                 (reinterpret_cast<uintptr_t>(dx32) & 15) == 0, "tdvc_dcn_col2im: workspace too small or unaligned");
   DcnBw p;
-  p.x = to_dev(*x); p.om = to_dev(*om); p.col = to_dev(*dcol); p.dom = to_dev(*dom); p.dx32 = dx32; p.G = groups;
-  const dim3 grid((unsigned)(((x->W + C2I_T - 1) / C2I_T) * ((x->H + C2I_T - 1) / C2I_T)), (unsigned)(x->N * groups));
-  hipLaunchKernelGGL(dcn_col2im_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  p.x = to_dev(*x); p.om = to_dev(*om); p.col = to_dev(*dcol); p.dom = to_dev(*dom); p.dx32 = dx32; p.wbuf = work; p.G = groups;
+  const int tiles_x = (x->W + C2I_T - 1) / C2I_T, tiles_y = (x->H + C2I_T - 1) / C2I_T;
+  const dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(x->N * groups));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(dcn_col2im_kernel, grid, dim3(64), 0, st, p);
+  hipLaunchKernelGGL(dcn_window_gather_kernel, g1((long)x->N * groups * x->H * x->W), dim3(256), 0, st, p, tiles_x, tiles_y);
   return tdvc_launch_status("tdvc_dcn_col2im");
 }

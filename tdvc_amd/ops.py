@@ -567,19 +567,24 @@ def dcn_columns(x: FM, om: FM, groups: int) -> FM:
 
 
 def dcn_col2im(x: FM, om: FM, dcol: FM, groups: int, dom: FM) -> FM:
-    """-> dx as an fp32 FM (fresh, float-atomic scatter); offset / mask gradients accumulate into `dom`"""
+    """-> dx as an fp32 FM (fresh; scatter through per-tile windows); offset / mask gradients accumulate into `dom`"""
     dx32 = FM.zeros(x.N, x.H, x.W, x.C, dtype=torch.float32, device=x.t.device)
+    lib = L.lib()
+    nwork = lib.tdvc_dcn_col2im_work_floats(x.N, x.H, x.W, groups)
+    work = torch.empty((nwork,), dtype=torch.float32, device=x.t.device)
     d1, d2, d3, d4 = x.desc(), om.desc(), dcol.desc(), dom.desc()
-    L.check(L.lib().tdvc_dcn_col2im(C.byref(d1), C.byref(d2), C.byref(d3), groups, dx32.t.data_ptr(), C.byref(d4), _stream()), "dcn_col2im")
+    L.check(lib.tdvc_dcn_col2im(C.byref(d1), C.byref(d2), C.byref(d3), groups, dx32.t.data_ptr(), C.byref(d4), work.data_ptr(), nwork, _stream()),
+            "dcn_col2im")
     return dx32
 
 
 def dcn_column_conv(pc: PackedConv, groups: int) -> PackedConv:
-    """the DCN weight (cout, 8G, 3, 3) as a 1x1 conv over the 72G column channels k = t*8G + c (weight offset c*9 + t)"""
+    """the DCN weight (cout, 8G, 3, 3) as a 1x1 conv over the 72G column channels k = g*72 + t*8 + j, input channel
+    c = g*8 + j (weight offset c*9 + t)"""
     cp = pc.__dict__.get("_colpc")
     if cp is None:
         cin = 8 * groups
-        chan = np.array([c * 9 + t for t in range(9) for c in range(cin)], dtype=np.int64)
+        chan = np.array([(g * 8 + j) * 9 + t for g in range(groups) for t in range(9) for j in range(8)], dtype=np.int64)
         lay = convpack.WeightLayout(pc.cout, 9 * cin, 1, 1, np.arange(pc.cout, dtype=np.int64) * cin * 9, chan, np.zeros(1, dtype=np.int64))
         cp = pack_conv(pc.wsrc, None, stride=1, pad=0, layout=lay, param_w=pc.param_w)
         pc.__dict__["_colpc"] = cp

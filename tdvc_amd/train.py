@@ -98,8 +98,9 @@ class TrainStep:
         self.main_params = [named[n] for n in main]
         self.aux_params = [named[n] for n in aux]
         self.buckets = GradBuckets(self.main_params)
-        self.optimizer = torch.optim.Adam(self.main_params, lr=lr)
-        self.aux_optimizer = torch.optim.Adam(self.aux_params, lr=10 * lr)          # utils.py:110-112
+        fused = all(p.is_cuda for p in self.main_params + self.aux_params)          # one multi-tensor kernel per step
+        self.optimizer = torch.optim.Adam(self.main_params, lr=lr, fused=fused)
+        self.aux_optimizer = torch.optim.Adam(self.aux_params, lr=10 * lr, fused=fused)          # utils.py:110-112
 
     def _forward_backward(self, input_image, refer_frames):
         """forward, loss seeds, backward: gradients accumulate into the (zeroed) buckets"""
@@ -143,9 +144,14 @@ class TrainStep:
             self._eager_steps += 1
         mse = (diff * diff).mean()
         self.buckets.all_reduce_mean()
-        finite = all(bool(torch.isfinite(b).all()) for b in self.buckets.buckets)      # after the mean: every rank agrees
+        # clip_grad_norm_(main params, clip) on the flat buckets: the global 2-norm is also the finiteness test (after the
+        # mean, so every rank agrees)
+        gnorm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(b) for b in self.buckets.buckets]))
+        finite = bool(torch.isfinite(gnorm))
         if finite:
-            gnorm = torch.nn.utils.clip_grad_norm_(self.main_params, self.clip)
+            coef = torch.clamp(self.clip / (gnorm + 1e-6), max=1.0)
+            for b in self.buckets.buckets:
+                b.mul_(coef)
             self.optimizer.step()
             self._clean_steps += 1
             if self.dynamic_scale and self._clean_steps % self.growth_interval == 0:
