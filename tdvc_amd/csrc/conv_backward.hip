@@ -99,6 +99,7 @@ struct WgradParams {
   int square_x;                                 // contract with x^2 (GDN norm pool: dgamma = sum dnorm * x^2)
   float* work;                                  // [P][ntaps_all][co_tiles*64][ci_tiles*32]
   float* bwork;                                 // [P][co_tiles*64] column sums of dY (bias gradient), or null
+  long long* stamps;                            // diagnostic: per (workgroup, wave) cycles per phase, or null
 };
 
 typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
@@ -139,39 +140,54 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int GL = WG_TH * WG_TW * (WG_CO / 8) / 256;             // 8 dY pieces per thread
   half8 gr[GL], xr[XL];
   const int x_items = p.tih * p.tiw * (WG_CI / 8);
-  auto prefetch = [&](int blk) {
+  // per-thread piece geometry is block-invariant: dY piece j = pixel (row j, column tid >> 3), channels 8 * (tid & 7);
+  // X piece j = tile pixel (tid >> 2) + 64 j -> (row, column) computed once
+  // Loads are unconditional (clamped addresses) and the out-of-range pieces are zeroed when they are written to LDS:
+  // a load under a branch made the compiler wait for it at the join (s_waitcnt vmcnt(0) after every pair of loads).
+  const int g_ox = tid >> 3;
+  const bool g_cok = co0 + (tid & 7) * 8 < p.g.C;
+  const int g_c = g_cok ? co0 + (tid & 7) * 8 : 0;
+  unsigned gmask = 0, xmask = 0;                                    // validity bits of the pieces in flight
+  int x_yy[XL], x_xx[XL];
+#pragma unroll
+  for (int j = 0; j < XL; ++j) {
+    const int px = (tid >> 2) + 64 * j;
+    x_yy[j] = px / p.tiw;
+    x_xx[j] = px - x_yy[j] * p.tiw;
+    if (tid + j * 256 >= x_items) x_yy[j] = 1 << 20;                // beyond the tile: never in bounds
+  }
+  const bool x_cok = ci0 + (tid & 3) * 8 < p.x.C;
+  const int x_c = x_cok ? ci0 + (tid & 3) * 8 : 0;
+  const half_t *gbase = nullptr, *xbase = nullptr;                  // next block: image base + first tile pixel
+  int n_oy0 = 0, n_ox0 = 0, n_iy0 = 0, n_ix0 = 0;
+  auto next_block = [&](int blk) {
     const int n = blk / (p.blocks_x * p.blocks_y);
     const int rem = blk - n * (p.blocks_x * p.blocks_y);
     const int by = rem / p.blocks_x, bx = rem - by * p.blocks_x;
-    const int oy0 = by * WG_TH, ox0 = bx * WG_TW;
-    const int iy0 = oy0 * p.stride - p.pad, ix0 = ox0 * p.stride - p.pad;
+    n_oy0 = by * WG_TH; n_ox0 = bx * WG_TW;
+    n_iy0 = n_oy0 * p.stride - p.pad; n_ix0 = n_ox0 * p.stride - p.pad;
+    gbase = reinterpret_cast<const half_t*>(p.g.p) + (long)n * p.g.sn + g_c;
+    xbase = reinterpret_cast<const half_t*>(p.x.p) + (long)n * p.x.sn + x_c;
+  };
+  auto load_g = [&](int j) {
+    const int oy = n_oy0 + j, ox = n_ox0 + g_ox;
+    const bool ok = oy < p.Ho && ox < p.Wo && g_cok;
+    gr[j] = *reinterpret_cast<const half8*>(gbase + (min(oy, p.Ho - 1) * p.Wo + min(ox, p.Wo - 1)) * p.g.sp);
+    gmask |= (ok ? 1u : 0u) << j;
+  };
+  auto load_x = [&](int j) {
+    const int iy = n_iy0 + x_yy[j], ix = n_ix0 + x_xx[j];
+    const bool ok = iy >= 0 && iy < p.x.H && ix >= 0 && ix < p.x.W && x_cok;
+    xr[j] = *reinterpret_cast<const half8*>(xbase + (min(max(iy, 0), p.x.H - 1) * p.x.W + min(max(ix, 0), p.x.W - 1)) * p.x.sp);
+    xmask |= (ok ? 1u : 0u) << j;
+  };
+  auto prefetch = [&](int blk) {
+    next_block(blk);
+    gmask = 0; xmask = 0;
 #pragma unroll
-    for (int j = 0; j < GL; ++j) {
-      const int it = tid + j * 256;
-      const int c8 = it & 7, px = it >> 3;
-      const int yy = px / WG_TW, xx = px - yy * WG_TW;
-      const int oy = oy0 + yy, ox = ox0 + xx, c = co0 + c8 * 8;
-      half8 v;
+    for (int j = 0; j < GL; ++j) load_g(j);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = (half_t)0.f;
-      if (oy < p.Ho && ox < p.Wo && c < p.g.C)
-        v = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(p.g.p) + (long)n * p.g.sn + ((long)oy * p.Wo + ox) * p.g.sp + c);
-      gr[j] = v;
-    }
-#pragma unroll
-    for (int j = 0; j < XL; ++j) {
-      const int it = tid + j * 256;
-      const int c8 = it & 3, px = it >> 2;
-      const int yy = px / p.tiw, xx = px - yy * p.tiw;
-      const int iy = iy0 + yy, ix = ix0 + xx, c = ci0 + c8 * 8;
-      half8 v;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = (half_t)0.f;
-      if (it < x_items && iy >= 0 && iy < p.x.H && ix >= 0 && ix < p.x.W && c < p.x.C)
-        v = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(p.x.p) + (long)n * p.x.sn + ((long)iy * p.x.W + ix) * p.x.sp + c);
-      if (p.square_x) v = v * v;
-      xr[j] = v;
-    }
+    for (int j = 0; j < XL; ++j) load_x(j);
   };
 
   // this wave's taps: wave, wave + 4, wave + 8 of the group; an absent tap reads tap 0's window and skips its MFMAs
@@ -192,11 +208,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
   for (int q = 0; q < 8; ++q) bs[q] = 0.f;
   if (worker < p.nblocks) prefetch(worker);
+  long long ph[6] = {0, 0, 0, 0, 0, 0}, tc = p.stamps ? clock64() : 0;
+  auto mark = [&](int k) { if (p.stamps) { const long long now = clock64(); ph[k] += now - tc; tc = now; } };
   for (int blk = worker; blk < p.nblocks; blk += nworkers) {
     __syncthreads();                                                // previous block's reads are done
+    mark(0);
+    half8 zero8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) zero8[q] = (half_t)0.f;
 #pragma unroll
     for (int j = 0; j < GL; ++j) {
       const int it = tid + j * 256;
+      gr[j] = ((gmask >> j) & 1u) ? gr[j] : zero8;
       *reinterpret_cast<half8*>(gt + (it >> 3) * PSG + (it & 7) * 16) = gr[j];
     }
     if (do_bias) {                                                  // this thread's pieces all carry channels 8*(tid&7) ..
@@ -208,14 +231,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
     for (int j = 0; j < XL; ++j) {
       const int it = tid + j * 256;
-      if (it < x_items) *reinterpret_cast<half8*>(xt + (it >> 2) * PSX + (it & 3) * 16) = xr[j];
+      half8 v = ((xmask >> j) & 1u) ? xr[j] : zero8;
+      if (p.square_x) v = v * v;
+      if (it < x_items) *reinterpret_cast<half8*>(xt + (it >> 2) * PSX + (it & 3) * 16) = v;
     }
+    gmask = 0; xmask = 0;
+    mark(1);
     __syncthreads();
-    if (blk + nworkers < p.nblocks) prefetch(blk + nworkers);
+    mark(2);
+    const bool more = blk + nworkers < p.nblocks;                   // wave-uniform
+    if (more) next_block(blk + nworkers);
+    mark(3);
     // ---- contraction: k-steps of 16 consecutive output pixels of one row.  Fragments of step ks+1 are read while the
-    // MFMAs of step ks run: with one workgroup per CU nothing else hides the LDS latency.
+    // MFMAs of step ks run (with one workgroup per CU nothing else hides the LDS latency), and the next block's global
+    // loads are issued piece by piece between the k-steps: their address arithmetic fills the MFMA shadow instead of
+    // running as a 4 k-cycle prologue in front of it.
     {
       constexpr int KS = WG_TH * (WG_TW / 16);
+      static_assert(KS == 2 * GL, "one dY piece per pair of k-steps");
       auto load = [&](int ks, half8 (&a)[2], half8 (&b)[3]) {
         const int yy = ks / (WG_TW / 16), kh = ks % (WG_TW / 16);
         const unsigned char* ap = abase + (yy * WG_TW + kh * 16) * PSG;
@@ -241,13 +274,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       };
       half8 a0[2], b0[3], a1[2], b1[3];
       load(0, a0, b0);
+#pragma unroll
       for (int ks = 0; ks < KS; ks += 2) {
         load(ks + 1, a1, b1);
         fma(a0, b0);
+        if (more && ks < KS / 2) {                                   // all pieces in the first half: they land before the next store
+          load_g(ks);
+          load_g(ks + 1);
+#pragma unroll
+          for (int j = ks / 2; j < XL; j += GL / 2) load_x(j);
+        }
         if (ks + 2 < KS) load(ks + 2, a0, b0);
         fma(a1, b1);
       }
     }
+    mark(4);
   }
   if (do_bias) {
     __syncthreads();
@@ -277,6 +318,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
           wk[((long)(tap0 + t) * COW + (co0 + m * 32 + row)) * CIW + (ci0 + col)] = acc[ai][m][i];
         }
     }
+  }
+  if (p.stamps && lane == 0) {
+    mark(5);
+    long long* o = p.stamps + (((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    for (int k = 0; k < 6; ++k) o[k] = ph[k];
   }
 }
 
@@ -351,6 +397,10 @@ extern "C" int tdvc_pack_conv_weights_batch(const tdvc_pack_job* jobs, const int
   return tdvc_launch_status("tdvc_pack_conv_weights_batch");
 }
 
+static long long* g_wg_stamp = nullptr;
+static long g_wg_stamp_cap = 0;
+extern "C" void tdvc_debug_set_stamp_buffer_wgrad(void* buf, int cap_workgroups) { g_wg_stamp = (long long*)buf; g_wg_stamp_cap = cap_workgroups; }
+
 static int wgrad_workers(int co_tiles, int ci_tiles, int groups, int nblocks, int ntaps) {
   int w = 1024 / (co_tiles * ci_tiles * groups);      // ~4 workgroups per CU over the whole launch
   const long dw_bytes = (long)co_tiles * WG_CO * ci_tiles * WG_CI * ntaps * 4;
@@ -381,6 +431,7 @@ extern "C" int tdvc_conv_wgrad_bias(const tdvc_fmap* g, const tdvc_fmap* x, int 
   const int cin = x->C;
   const int Ho = (x->H + 2 * pad - kh) / stride + 1, Wo = (x->W + 2 * pad - kw) / stride + 1;
   TDVC_CHECK(Ho == g->H && Wo == g->W, "tdvc_conv_wgrad: dY is %dx%d, conv output is %dx%d", g->H, g->W, Ho, Wo);
+  TDVC_CHECK((long)x->H * x->W * x->sp < 2147483647L && (long)g->H * g->W * g->sp < 2147483647L, "tdvc_conv_wgrad: image too large for 32-bit element offsets");
   TDVC_CHECK(work_floats >= tdvc_conv_wgrad_work_floats(cout, cin, ntaps, x->N, Ho, Wo), "tdvc_conv_wgrad: workspace too small");
   WgradParams p;
   p.g = to_dev(*g); p.x = to_dev(*x);
@@ -401,6 +452,7 @@ extern "C" int tdvc_conv_wgrad_bias(const tdvc_fmap* g, const tdvc_fmap* x, int 
   const int groups = (ntaps + WG_MAXT - 1) / WG_MAXT;
   const int workers = wgrad_workers(p.co_tiles, p.ci_tiles, groups, p.nblocks, ntaps);
   p.bwork = db ? work + (long)workers * p.co_tiles * WG_CO * p.ci_tiles * WG_CI * ntaps : nullptr;
+  p.stamps = (g_wg_stamp && (long)p.co_tiles * p.ci_tiles * workers * groups <= g_wg_stamp_cap) ? g_wg_stamp : nullptr;
   const int xl = (p.tih * p.tiw * (WG_CI / 8) + 255) / 256;
   TDVC_CHECK(xl <= 18, "tdvc_conv_wgrad: X tile of %dx%d pixels needs %d pieces per thread (max 18)", p.tih, p.tiw, xl);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
