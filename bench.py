@@ -200,7 +200,7 @@ def train_leg(a, rank, world, dev, dist):
             "unit": "samples/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{B} x 256x256 P-frame samples per rank (septuplet frame 3, refs [I,I,x1,x2]), full fwd/bwd incl. entropy models",
-                       "global_batch": B * a.gpus, "parallelism": f"data-parallel x{a.gpus} (RCCL gradient mean, 64 MB buckets)",
+                       "global_batch": B * a.gpus, "parallelism": f"data-parallel x{a.gpus} (RCCL gradient mean, 16 MB buckets in gradient-completion order, all-reduced under the backward sweep)",
                        "weights": "closed-form filler (no checkpoint ships)"},
             "whole_step_tflops": round(flop_step * a.steps / dt / 1e12, 2),
             "rd_loss_last": round(log["rd_loss"], 4), "grad_norm_last": round(log["grad_norm"], 3)}))

@@ -29,6 +29,12 @@ class Tape:
         self.nograd: set[int] = set()             # base buffers that need no gradient (network inputs)
         self.loss_scale = float(loss_scale)
         self.rate_grad = 0.0                      # dLoss/d(bits) of every rate term, set before backward() (1 / pixels for bpp)
+        # data-parallel overlap (train.GradBuckets): which backward node writes a parameter's gradient last, and a hook
+        # after every node so a finished bucket's all-reduce starts under the rest of the sweep
+        self.touch_log: dict[int, int] | None = None
+        self.on_node_done = None
+        self._cur = -1
+        self.n_backward_nodes = 0
 
     # ------------------------------------------------------------------ gradient views
     def _base(self, t: torch.Tensor) -> torch.Tensor:
@@ -56,6 +62,12 @@ class Tape:
     def add(self, fn):
         self.nodes.append(fn)
 
+    def touch(self, *params):
+        """the running backward node writes these parameters' gradients"""
+        if self.touch_log is not None:
+            for q in params:
+                self.touch_log[id(q)] = self._cur
+
     @property
     def inv_scale(self) -> float:
         return 1.0 / self.loss_scale
@@ -64,10 +76,15 @@ class Tape:
     def backward(self):
         prev, ops._IN_BACKWARD = ops._IN_BACKWARD, True
         try:
-            for fn in reversed(self.nodes):
+            self.n_backward_nodes = len(self.nodes)
+            for k, fn in enumerate(reversed(self.nodes)):
+                self._cur = k
                 fn()
+                if self.on_node_done is not None:
+                    self.on_node_done(k)
         finally:
             ops._IN_BACKWARD = prev
+            self._cur = -1
         self.nodes.clear()
 
 
@@ -75,6 +92,9 @@ def param_grad(p: torch.Tensor) -> torch.Tensor:
     """fp32 gradient accumulator of a parameter (created zeroed)"""
     if p.grad is None:
         p.grad = torch.zeros_like(p, dtype=torch.float32)
+    t = ops.TAPE
+    if t is not None:
+        t.touch(p)
     return p.grad
 
 
@@ -232,6 +252,7 @@ def record_gdn(tape: Tape, x: FM, pc, y: FM, res, gdn):
         dbeta = torch.zeros_like(pc.bsrc)
         ops.conv_wgrad(pc, dn, x, dgamma.view(-1), scale=tape.inv_scale, square_x=True, db=dbeta)
         owner.accumulate_param_grads(dgamma.view(dgamma.shape[0], dgamma.shape[1]), dbeta)
+        tape.touch(*owner.parameters())
 
     tape.add(bwd)
 
@@ -247,6 +268,7 @@ def record_eb_forward(tape: Tape, z: FM, params: torch.Tensor, z_hat: FM, noise)
         dp = torch.zeros_like(params)
         ops.eb_backward(z, params, noise, tape.rate_grad * tape.loss_scale, dz, dp)
         owner.accumulate_param_grads(dp * tape.inv_scale)
+        tape.touch(*owner.parameters())
 
     tape.add(bwd)
 

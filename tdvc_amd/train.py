@@ -41,41 +41,78 @@ def refresh_packed(model: torch.nn.Module) -> None:
 class GradBuckets:
     """Flat fp32 buckets over the parameter gradients: `param.grad` tensors become views into a few large buffers,
     so the data-parallel exchange is a handful of large all-reduces (xGMI rings are per-link bound: few, large
-    messages) and `zero_grad` is one memset per bucket."""
+    messages) and `zero_grad` is one fill per bucket.
 
-    def __init__(self, params, bucket_bytes: int = 64 << 20):
+    Overlap with the backward sweep: `reorder(ready)` re-lays the buckets in the order the tape finishes
+    the gradients (`ready[id(p)]` = index of the last backward node that writes p's gradient, `Tape.touch_log`);
+    `node_done(k)` — the tape's per-node hook — then starts the async all-reduce of every bucket whose last writer was
+    node k, so the exchange of the late layers runs under the backward of the early ones; `all_reduce_mean()` starts
+    whatever has not been started, waits, and divides by the world size."""
+
+    def __init__(self, params, bucket_bytes: int = 16 << 20):
         self.params = [p for p in params if p.requires_grad]
-        self.buckets = []
+        self.bucket_bytes = int(bucket_bytes)
+        self._layout([(p, -1) for p in self.params], keep=False)
+
+    def _layout(self, order, keep: bool):
+        """order: [(param, ready index)] in bucket order; keep: carry the current gradient values over"""
+        old = {id(p): p.grad for p, _ in order} if keep else {}
+        self.buckets, self.ready_at, self._works = [], [], {}
         cur, cur_n = [], 0
-        for p in self.params:
-            if cur and (cur_n + p.numel()) * 4 > bucket_bytes:
-                self._close(cur, cur_n)
+        for p, r in order:
+            if cur and (cur_n + p.numel()) * 4 > self.bucket_bytes:
+                self._close(cur, cur_n, old)
                 cur, cur_n = [], 0
-            cur.append(p)
+            cur.append((p, r))
             cur_n += p.numel()
         if cur:
-            self._close(cur, cur_n)
+            self._close(cur, cur_n, old)
+        self._by_ready = {}
+        for i, r in enumerate(self.ready_at):
+            self._by_ready.setdefault(r, []).append(i)
 
-    def _close(self, ps, n):
-        flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
+    def _close(self, ps, n, old):
+        flat = torch.zeros(n, dtype=torch.float32, device=ps[0][0].device)
         off = 0
-        for p in ps:
-            p.grad = flat[off:off + p.numel()].view_as(p)
+        for p, _ in ps:
+            v = flat[off:off + p.numel()].view_as(p)
+            if old.get(id(p)) is not None:
+                v.copy_(old[id(p)])
+            p.grad = v
             off += p.numel()
         self.buckets.append(flat)
+        self.ready_at.append(max(r for _, r in ps))
+
+    def reorder(self, ready: dict, n_nodes: int):
+        """buckets in gradient-completion order; parameters the tape never touched (zero gradient) go first"""
+        self.n_nodes = int(n_nodes)
+        order = sorted(((p, ready.get(id(p), -1)) for p in self.params), key=lambda t: t[1])
+        self._layout(order, keep=True)
 
     def zero(self):
         for b in self.buckets:
             b.zero_()
 
+    @staticmethod
+    def _distributed() -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def node_done(self, k: int):
+        for i in self._by_ready.get(k, ()):
+            if self._distributed() and i not in self._works:
+                self._works[i] = dist.all_reduce(self.buckets[i], op=dist.ReduceOp.SUM, async_op=True)
+
     def all_reduce_mean(self):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not self._distributed():
             return
         world = dist.get_world_size()
-        works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True) for b in self.buckets]
-        for w, b in zip(works, self.buckets):
-            w.wait()
+        for i, b in enumerate(self.buckets):
+            if i not in self._works:
+                self._works[i] = dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True)
+        for i, b in enumerate(self.buckets):
+            self._works[i].wait()
             b.mul_(1.0 / world)
+        self._works = {}
 
 
 class TrainStep:
@@ -87,6 +124,7 @@ class TrainStep:
         self.model = model
         self.use_graph, self.graph_warmup, self._eager_steps = bool(graph), int(graph_warmup), 0
         self._graph = None
+        self._ready, self._n_nodes = None, None      # gradient-completion order, learnt on step 0
         self.lam = float(train_lambda)
         self.loss_scale = float(loss_scale)
         self.clip = float(clip)
@@ -102,17 +140,25 @@ class TrainStep:
         self.optimizer = torch.optim.Adam(self.main_params, lr=lr, fused=fused)
         self.aux_optimizer = torch.optim.Adam(self.aux_params, lr=10 * lr, fused=fused)          # utils.py:110-112
 
-    def _forward_backward(self, input_image, refer_frames):
+    def _forward_backward(self, input_image, refer_frames, capturing: bool = False):
         """forward, loss seeds, backward: gradients accumulate into the (zeroed) buckets"""
         B, _, H, W = input_image.shape
         self.buckets.zero()
         with autograd.record(self.loss_scale) as tape:
+            if self._ready is None:
+                tape.touch_log = {}                                  # first step: learn when each gradient is final
+            elif not capturing:
+                # later steps: all-reduce finished buckets under the rest of the sweep (same tape shape as the logged step)
+                tape.on_node_done = lambda k: self.buckets.node_done(k) if tape.n_backward_nodes == self._n_nodes else None
             recon, bpp_res, bpp_mv, _, _ = self.model(input_image, refer_frames, True)
             diff = recon - input_image.float()
             # d(lambda * MSE)/d recon, scaled; the rate terms are seeded through tape.rate_grad
             tape.grad_tensor(recon).copy_(diff * (2.0 * self.lam * self.loss_scale / diff.numel()))
             tape.rate_grad = 1.0 / float(B * H * W)
             tape.backward()
+        if self._ready is None:
+            self._ready, self._n_nodes = tape.touch_log, tape.n_backward_nodes
+            self.buckets.reorder(self._ready, self._n_nodes)
         # MSE itself is reduced by the caller, outside a captured graph: torch's multi-block reduction zeroes its
         # semaphores with a memset node, and on this ROCm build the first replay after other work on the stream returned
         # partial sums (tools/dbg_graph6.py); the gradients never depended on that scalar
@@ -124,7 +170,7 @@ class TrainStep:
         self._graph_scale = self.loss_scale
         torch.cuda.synchronize()
         with torch.cuda.graph(self._graph):
-            self._static_out = self._forward_backward(*self._static_in)
+            self._static_out = self._forward_backward(*self._static_in, capturing=True)
 
     def __call__(self, input_image: torch.Tensor, refer_frames: torch.Tensor) -> dict:
         model = self.model

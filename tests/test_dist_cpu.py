@@ -65,6 +65,24 @@ def _grad_worker(rank, world, port, q):
     views = all(p.grad.untyped_storage().data_ptr() in {b.untyped_storage().data_ptr() for b in gb.buckets} for p in params)
     gb.zero()
     zeroed = all(float(p.grad.abs().max()) == 0.0 for p in params)
+    # overlap machinery: buckets re-laid in gradient-completion order, all-reduces started from the backward sweep's
+    # per-node hook (here a fake sweep of 6 nodes; parameter 3 is never touched), values carried over by reorder()
+    for i, p in enumerate(params):
+        p.grad.fill_(float(i))
+    ready = {id(params[4]): 0, id(params[2]): 2, id(params[0]): 5, id(params[1]): 5}
+    gb.reorder(ready, 6)
+    carried = all(float(p.grad.flatten()[0]) == float(i) for i, p in enumerate(params))
+    order_ok = gb.ready_at == sorted(gb.ready_at) and gb.ready_at[0] == -1 and gb.ready_at[-1] == 5
+    for i, p in enumerate(params):
+        p.grad.fill_(float(rank + 1) * (i + 1))
+    started = []
+    for k in range(6):
+        gb.node_done(k)
+        started.append(len(gb._works))
+    gb.all_reduce_mean()
+    ok2 = all(torch.allclose(p.grad, torch.full_like(p, mean * (i + 1))) for i, p in enumerate(params))
+    overlap_ok = carried and order_ok and ok2 and started[0] >= 1 and started[-1] >= started[0] and not gb._works
+    ok = ok and overlap_ok
     if rank == 0:
         q.put((ok, views, zeroed, len(gb.buckets)))
     dist.barrier()
