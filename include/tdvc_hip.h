@@ -376,6 +376,18 @@ int64_t tdvc_dcn_col2im_work_floats(int N, int H, int W, int groups);
 int tdvc_dcn_col2im(const tdvc_fmap* x, const tdvc_fmap* om, const tdvc_fmap* dcol, int groups, float* dx32, const tdvc_fmap* dom,
                     float* work, int64_t work_floats, void* stream);
 
+/* ---------------------------------------------------------------- quality metrics (evaluation loop)
+ * One level of MS-SSIM as main/model/ms_ssim_torch.py:33-83 computes it on a float32 NCHW pair: valid separable
+ * filter `win` (HOST array of win_size taps, odd, <= 15) of X, Y, X^2, Y^2, XY; ssim_out[n] / cs_out[n] = the means of
+ * the ssim / cs maps over (C, H - win + 1, W - win + 1), BEFORE the reference's (v + 1) / 2.  x, y, outputs and `work`
+ * (tdvc_ssim_level_work_floats floats) are device memory.  tdvc_avgpool2_pad_f32 is the pooling between levels
+ * (:178-180): kernel 2, stride 2, padding (H % 2, W % 2) with the zeros counted; out is
+ * [planes][(H + 2*(H%2) - 2) / 2 + 1][(W + 2*(W%2) - 2) / 2 + 1]. */
+int64_t tdvc_ssim_level_work_floats(int N, int C, int H, int W, int win_size);
+int tdvc_ssim_level(const float* x, const float* y, int N, int C, int H, int W, const float* win, int win_size,
+                    float c1, float c2, float* ssim_out, float* cs_out, float* work, int64_t work_floats, void* stream);
+int tdvc_avgpool2_pad_f32(const float* x, int64_t planes, int H, int W, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,10 +21,18 @@ import time
 import torch
 import yaml
 
+from .. import metrics
 from ..codec_utils import crop, pad, psnr
 from ..model import VideoCompressor
 from ..parallel import gather_frame_stats, shard_gops
 from ..synth import fill_parameters, make_gop, ref_list
+
+
+def _msssim(rc: torch.Tensor, xc: torch.Tensor) -> float:
+    """predict.py:92-94: ms_ssim(recon.float(), input, data_range=1.0); the 5-level pyramid needs >= 176 pixels a side"""
+    if min(rc.shape[-2:]) < 176:
+        return float("nan")
+    return float(metrics.ms_ssim(rc.float(), xc.float(), data_range=1.0))
 
 
 def code_gop(net, frames: torch.Tensor, enable_amp: bool = True, bitstream_dir: str | None = None, tag: str = ""):
@@ -52,13 +60,13 @@ def code_gop(net, frames: torch.Tensor, enable_amp: bool = True, bitstream_dir: 
             refs.append(recon)
             rc, xc = crop(recon, (h, w)), crop(x, (h, w))
             bpp = 8.0 * nbytes / (x.shape[-2] * x.shape[-1])
-            stats.append({"frame": t, "psnr": psnr(rc, xc), "bpp": bpp, "bpp_mv": 8.0 * (len(flat[0]) + len(flat[1])) / (x.shape[-2] * x.shape[-1]),
+            stats.append({"frame": t, "psnr": psnr(rc, xc), "msssim": _msssim(rc, xc), "bpp": bpp, "bpp_mv": 8.0 * (len(flat[0]) + len(flat[1])) / (x.shape[-2] * x.shape[-1]),
                           "bpp_res": 8.0 * (len(flat[2]) + len(flat[3])) / (x.shape[-2] * x.shape[-1]), "bytes": nbytes})
             continue
         recon, bpp_res, bpp_mv = net(x, ref_list(refs), enable_amp)
         refs.append(recon)                                   # padded reconstruction re-enters the list (:68)
         rc, xc = crop(recon, (h, w)), crop(x, (h, w))
-        stats.append({"frame": t, "psnr": psnr(rc, xc), "bpp": float(bpp_res + bpp_mv),
+        stats.append({"frame": t, "psnr": psnr(rc, xc), "msssim": _msssim(rc, xc), "bpp": float(bpp_res + bpp_mv),
                       "bpp_mv": float(bpp_mv), "bpp_res": float(bpp_res)})
     return stats
 
@@ -73,6 +81,10 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--out", default=None)
     ap.add_argument("--bitstream-dir", default=None, help="really encode / write / read / decode every frame into this directory")
+    ap.add_argument("--dataset-root", default=None, help="ori_img/ + compress_img_bpg/ tree (tdvc_amd.data); default: synthetic GOPs")
+    ap.add_argument("--val-dataset", default="UVG", choices=("UVG", "MCL-JCV", "HEVC"), help="with --dataset-root (predict.py:154-166)")
+    ap.add_argument("--cls", default="B", help="HEVC class A..E")
+    ap.add_argument("--train-lambda", type=int, default=2048, help="selects the BPG QP of the I-frames (dataset.py:25-36)")
     a = ap.parse_args()
     opt = {"model": "pnet", "pretrain": a.pretrain, "val_dataset": "synthetic", "class": "-", "enable_amp": True}
     if a.cfg:
@@ -92,9 +104,22 @@ def main():
     net = net.to(dev).eval()
     t0 = time.time()
     stats = []
+    dataset = None
+    if a.dataset_root:                                   # predict.py:154-166: GOP 12 (UVG, MCL-JCV) / 10 (HEVC), testfull
+        from .. import data
+        opt.update(val_dataset=a.val_dataset, **{"class": a.cls if a.val_dataset == "HEVC" else "-"})
+        dataset = (data.HEVCDataSet(a.dataset_root, a.train_lambda, 10, a.cls, testfull=True, isTrain=False) if a.val_dataset == "HEVC" else
+                   data.UVGDataSet(a.dataset_root, a.train_lambda, 12, testfull=True, isTrain=False))
     with torch.no_grad():
-        for g in shard_gops(a.gops, world, rank):
-            frames = make_gop(2000 + g, a.gop_size, a.height, a.width).to(dev)
+        for g in shard_gops(len(dataset) if dataset is not None else a.gops, world, rank):
+            if dataset is not None:
+                inp, ref_image, ref_bpp, ref_psnr, ref_msssim = dataset[g][:5]
+                frames = torch.cat([torch.from_numpy(ref_image)[None], torch.from_numpy(inp)]).to(dev)
+                # the BPG I-frame enters the averages with its own bpp / PSNR / MS-SSIM (predict.py:46-49)
+                stats.append({"gop": g, "frame": 0, "psnr": float(ref_psnr), "msssim": float(ref_msssim), "bpp": float(ref_bpp),
+                              "bpp_mv": 0.0, "bpp_res": 0.0})
+            else:
+                frames = make_gop(2000 + g, a.gop_size, a.height, a.width).to(dev)
             if a.bitstream_dir:
                 os.makedirs(a.bitstream_dir, exist_ok=True)
             for s in code_gop(net, frames, bool(opt["enable_amp"]), a.bitstream_dir, f"gop{g:03d}_"):
@@ -105,11 +130,11 @@ def main():
     if rank == 0:
         n = max(1, len(allstats))
         res = {"frames": len(allstats), "bpp": sum(s["bpp"] for s in allstats) / n,
-               "psnr": sum(s["psnr"] for s in allstats) / n, "seconds": time.time() - t0, "cfg": opt}
+               "psnr": sum(s["psnr"] for s in allstats) / n, "msssim": sum(s["msssim"] for s in allstats) / n, "seconds": time.time() - t0, "cfg": opt}
         print(json.dumps(res))
         if a.out:
             with open(a.out, "w") as f:
-                f.write("bpp : %.6f\n\npsnr : %.6f\n" % (res["bpp"], res["psnr"]))
+                f.write("bpp : %.6f\n\npsnr : %.6f\n\nmsssim : %.6f\n" % (res["bpp"], res["psnr"], res["msssim"]))       # predict.py:102
                 f.write("cfg :\n" + json.dumps(opt, indent=4) + "\ncost_time :\n" + str(res["seconds"]) + "\n")
     if world > 1:
         dist.barrier()

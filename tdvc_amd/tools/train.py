@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--save-dir", default="")
     ap.add_argument("--save-every", type=int, default=10000)
     ap.add_argument("--seed", type=int, default=1000)
+    ap.add_argument("--vimeo", default="", help="Vimeo-septuplet root (<dir>/<clip>/im1..7.png): tdvc_amd.data.DataSet with the "
+                                                "reference's sample rule and augmentation (train.py:78-80); default: synthetic septuplets")
+    ap.add_argument("--num-workers", type=int, default=4)
     a = ap.parse_args()
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
@@ -71,13 +74,41 @@ def main():
 
     pool, cursor = [], 0
     t0 = time.time()
+    loader = None
+    if a.vimeo:                                         # train.py:78-80: shuffled DataLoader over the septuplet samples
+        from torch.utils.data import DataLoader
+        from torch.utils.data.distributed import DistributedSampler
+
+        from ..data import DataSet
+        ds = DataSet(a.vimeo, resize_size=a.size, seed=a.seed + rank)
+        sampler = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, seed=a.seed) if world > 1 else None
+
+        def _reseed(worker_id):                         # every loader worker draws its own augmentations
+            import numpy as np
+            from torch.utils.data import get_worker_info
+            get_worker_info().dataset.rng = np.random.default_rng(a.seed + 7919 * rank + 104729 * (worker_id + 1))
+        dl = DataLoader(ds, batch_size=a.batch, shuffle=sampler is None, sampler=sampler, num_workers=a.num_workers, drop_last=True,
+                        worker_init_fn=_reseed)
+
+        def _cycle():
+            epoch = 0
+            while True:
+                if sampler is not None:
+                    sampler.set_epoch(epoch)
+                yield from dl
+                epoch += 1
+        loader = _cycle()
     for it in range(a.iters):
-        while len(pool) < a.batch:                  # every rank walks its own septuplets (seed = base + global index)
-            pool += septuplet_samples(make_gop(a.seed + (cursor * world + rank), 7, a.size, a.size))
-            cursor += 1
-        batch, pool = pool[:a.batch], pool[a.batch:]
-        x = torch.stack([b[0] for b in batch]).to(dev)
-        refs = torch.stack([b[1] for b in batch]).to(dev)
+        if loader is not None:
+            x, refs = next(loader)
+            x, refs = x.to(dev), refs.to(dev)
+        else:
+            while len(pool) < a.batch:                  # every rank walks its own septuplets (seed = base + global index)
+                pool += septuplet_samples(make_gop(a.seed + (cursor * world + rank), 7, a.size, a.size))
+                cursor += 1
+            batch, pool = pool[:a.batch], pool[a.batch:]
+            x = torch.stack([b[0] for b in batch]).to(dev)
+            refs = torch.stack([b[1] for b in batch]).to(dev)
         log = step(x, refs)
         if rank == 0:
             psnr = 10.0 * torch.log10(torch.tensor(1.0 / max(log["mse"], 1e-12))).item()
