@@ -16,6 +16,21 @@ def _ops():
     return ops
 
 
+@pytest.fixture(autouse=True, params=["v9", "tiled"])
+def small_map_kernel(request):
+    """every case of this module runs twice: with the small-map split-K kernel (conv_mfma_v9, the product dispatch for
+    <= 8192 output pixels) and with it switched off, so the tiled kernels keep their small-shape coverage"""
+    import ctypes
+
+    from tdvc_amd import _lib
+    fn = _lib.lib().tdvc_debug_enable_conv_v9
+    fn.argtypes = [ctypes.c_int]
+    fn.restype = None
+    fn(1 if request.param == "v9" else 0)
+    yield request.param
+    fn(1)
+
+
 CASES = [
     # name, N, cin, cout, k, stride, pad, H, W
     ("3x3_64_64", 1, 64, 64, 3, 1, 1, 24, 40),
