@@ -113,8 +113,10 @@ bool conv_v9_eligible(const tdvc_conv_desc* d, int Ho, int Wo) {
   static const bool off = getenv("TDVC_CONV_NO_V9") != nullptr || getenv("TDVC_CONV_V1") != nullptr;
   if (off || !g_v9_enabled || d->s2d) return false;
   const long px = (long)Ho * Wo * d->x.N;
+  static const long maxpx = getenv("TDVC_V9_MAX_PX") ? atol(getenv("TDVC_V9_MAX_PX")) : 8192;
+  static const long minpx = getenv("TDVC_V9_MIN_PX") ? atol(getenv("TDVC_V9_MIN_PX")) : 0;
   const long ksteps = (long)((d->x.C + d->ck - 1) / d->ck) * ((d->ntaps * (d->ck / 8) + 1) / 2);
-  return px <= 8192 && ksteps >= 4 && (d->x.C % 8) == 0;
+  return px <= maxpx && px >= minpx && ksteps >= 4 && (d->x.C % 8) == 0;
 }
 
 template <int CK8>

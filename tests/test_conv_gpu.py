@@ -50,6 +50,11 @@ CASES = [
     ("1x1_426_341", 1, 426, 341, 1, 1, 0, 8, 15),
     ("3x3_64_216", 1, 64, 216, 3, 1, 1, 16, 32),
     ("3x3_192_256", 1, 192, 256, 3, 1, 1, 8, 12),
+    ("3x3_128_128_4x4", 2, 128, 128, 3, 1, 1, 4, 4),            # hyper-analysis sizes at a 64x64 crop
+    ("3x3_128_128_2x2", 1, 128, 128, 3, 1, 1, 2, 2),
+    ("3x3_128_128_1x1", 1, 128, 128, 3, 1, 1, 1, 1),
+    ("3x3_s2_128_128_4x4", 1, 128, 128, 3, 2, 1, 4, 4),
+    ("5x5_128_256_3x5", 1, 128, 256, 5, 1, 2, 3, 5),
 ]
 
 
