@@ -161,7 +161,7 @@ class TrainStep:
             self.buckets.reorder(self._ready, self._n_nodes)
         # MSE itself is reduced by the caller, outside a captured graph: torch's multi-block reduction zeroes its
         # semaphores with a memset node, and on this ROCm build the first replay after other work on the stream returned
-        # partial sums (tools/dbg_graph6.py); the gradients never depended on that scalar
+        # partial sums (tools/graph_reduce_repro.py); the gradients never depended on that scalar
         return diff, bpp_res.mean(), bpp_mv.mean()
 
     def _capture(self, input_image, refer_frames):
