@@ -35,6 +35,9 @@ class Tape:
         self.on_node_done = None
         self._cur = -1
         self.n_backward_nodes = 0
+        # weight / bias gradients are off the critical path of the sweep (nothing in the backward reads them): with a side
+        # stream they run next to the dgrad chain and fill the CUs the small layers leave idle
+        self.side = None
 
     # ------------------------------------------------------------------ gradient views
     def _base(self, t: torch.Tensor) -> torch.Tensor:
@@ -62,6 +65,24 @@ class Tape:
     def add(self, fn):
         self.nodes.append(fn)
 
+    def off_path(self, fn, *tensors):
+        """run `fn` (parameter-gradient kernels reading `tensors`) on the side stream, ordered after everything issued so far"""
+        if self.side is None:
+            return fn()
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            for t in tensors:
+                t.record_stream(self.side)        # the caching allocator must not hand these to the main stream meanwhile
+            fn()
+
+    def join(self):
+        """the main stream waits for the parameter-gradient kernels (before an all-reduce, the optimizer, the tape's end)"""
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+
     def touch(self, *params):
         """the running backward node writes these parameters' gradients"""
         if self.touch_log is not None:
@@ -83,6 +104,7 @@ class Tape:
                 if self.on_node_done is not None:
                     self.on_node_done(k)
         finally:
+            self.join()
             ops._IN_BACKWARD = prev
             self._cur = -1
         self.nodes.clear()
@@ -99,8 +121,9 @@ def param_grad(p: torch.Tensor) -> torch.Tensor:
 
 
 @contextlib.contextmanager
-def record(loss_scale: float = 1.0):
+def record(loss_scale: float = 1.0, side_stream=None):
     tape = Tape(loss_scale)
+    tape.side = side_stream
     prev, ops.TAPE = ops.TAPE, tape
     try:
         yield tape
@@ -140,10 +163,11 @@ def record_conv(tape: Tape, x: FM, pc, y, act, slope, res, res2, gdn, aux, squar
         elif act != ops.ACT_NONE:
             raise NotImplementedError(f"autograd: activation {act}")
         gq = ops.pixel_unshuffle(g) if pc.shuffle else g
+        tape.off_path(lambda: ops.conv_wgrad(pc, gq, x, param_grad(weight).view(-1), scale=tape.inv_scale,
+                                             db=param_grad(bias) if bias is not None else None),     # bias gradient from the same launch
+                      gq.t, x.t)
         if tape.needs_grad(x):
             ops.conv_dgrad(pc, gq, tape.grad(x), accumulate=True)
-        ops.conv_wgrad(pc, gq, x, param_grad(weight).view(-1), scale=tape.inv_scale,
-                       db=param_grad(bias) if bias is not None else None)       # bias gradient from the same launch
 
     tape.add(bwd)
 

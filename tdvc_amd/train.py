@@ -117,7 +117,8 @@ class GradBuckets:
 
 class TrainStep:
     def __init__(self, model, train_lambda: float = 2048.0, lr: float = 1e-4, loss_scale: float = 1024.0, clip: float = 2.0,
-                 dynamic_scale: bool = True, growth_interval: int = 2000, graph: bool = False, graph_warmup: int = 2):
+                 dynamic_scale: bool = True, growth_interval: int = 2000, graph: bool = False, graph_warmup: int = 2,
+                 side_stream: bool = True):
         """graph=True: after `graph_warmup` eager steps (they build every lazily packed form) the forward + backward of
         one step is captured into a HIP graph and replayed: ~2300 launches leave the Python interpreter's critical
         path.  Input shapes are then fixed; a loss-scale change re-captures."""
@@ -125,6 +126,8 @@ class TrainStep:
         self.use_graph, self.graph_warmup, self._eager_steps = bool(graph), int(graph_warmup), 0
         self._graph = None
         self._ready, self._n_nodes = None, None      # gradient-completion order, learnt on step 0
+        # weight-gradient kernels run on a side stream next to the dgrad chain (autograd.Tape.off_path)
+        self._side = torch.cuda.Stream() if (side_stream and torch.cuda.is_available()) else None
         self.lam = float(train_lambda)
         self.loss_scale = float(loss_scale)
         self.clip = float(clip)
@@ -140,16 +143,21 @@ class TrainStep:
         self.optimizer = torch.optim.Adam(self.main_params, lr=lr, fused=fused)
         self.aux_optimizer = torch.optim.Adam(self.aux_params, lr=10 * lr, fused=fused)          # utils.py:110-112
 
+    def _node_done(self, tape, k):
+        if tape.n_backward_nodes == self._n_nodes and k in self.buckets._by_ready and self.buckets._distributed():
+            tape.join()                                  # the side stream's weight gradients of this bucket are complete
+            self.buckets.node_done(k)
+
     def _forward_backward(self, input_image, refer_frames, capturing: bool = False):
         """forward, loss seeds, backward: gradients accumulate into the (zeroed) buckets"""
         B, _, H, W = input_image.shape
         self.buckets.zero()
-        with autograd.record(self.loss_scale) as tape:
+        with autograd.record(self.loss_scale, side_stream=self._side) as tape:
             if self._ready is None:
                 tape.touch_log = {}                                  # first step: learn when each gradient is final
             elif not capturing:
                 # later steps: all-reduce finished buckets under the rest of the sweep (same tape shape as the logged step)
-                tape.on_node_done = lambda k: self.buckets.node_done(k) if tape.n_backward_nodes == self._n_nodes else None
+                tape.on_node_done = lambda k: self._node_done(tape, k)
             recon, bpp_res, bpp_mv, _, _ = self.model(input_image, refer_frames, True)
             diff = recon - input_image.float()
             # d(lambda * MSE)/d recon, scaled; the rate terms are seeded through tape.rate_grad

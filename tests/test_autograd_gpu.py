@@ -417,6 +417,22 @@ def test_full_model_backward_and_steps(report):
     tot = _rel(gd, gr)
     report(f"full model: whole-gradient rel L2 err {tot:.3e}, norms device {float(gd.norm()):.4e} oracle {float(gr.norm()):.4e}")
     assert tot < 5e-2 and errs[int(0.9 * len(errs))][0] < 0.15
+    # the same sweep with the weight-gradient kernels on a side stream (Tape.off_path, what TrainStep does): every
+    # parameter gradient bit-identical -- a missing dependency between the streams would show here
+    first = {k: p.grad.clone() for k, p in dev.named_parameters() if p.grad is not None}
+    for rep_ in range(2):
+        for p in dev.parameters():
+            p.grad = None
+        with autograd.record(side_stream=torch.cuda.Stream()) as tape:
+            r2, _, _, _, _ = dev(x.cuda(), refs.cuda(), True, noise=nf)
+            d2 = r2 - x.cuda()
+            tape.grad_tensor(r2).copy_(d2 * (2.0 * lam / d2.numel()))
+            tape.rate_grad = 1.0 / float(B * H * W)
+            tape.backward()
+        torch.cuda.synchronize()
+        bad = [k for k, p in dev.named_parameters() if p.grad is not None and k in first and not torch.equal(p.grad, first[k])]
+        assert not bad, f"side-stream sweep differs in {len(bad)} tensors, e.g. {bad[:4]}"
+    report(f"full model: side-stream weight gradients bit-identical to the single-stream sweep ({len(first)} tensors, 2 repeats)")
     # three optimisation steps: finite, and the loss moves down on a fixed sample
     for p in dev.parameters():
         p.grad = None
