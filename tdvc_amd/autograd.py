@@ -72,10 +72,12 @@ class Tape:
         main = torch.cuda.current_stream()
         ev = torch.cuda.Event()
         ev.record(main)
+        # the operands stay referenced until the tape dies, i.e. until after join(): the caching allocator cannot hand
+        # them to the main stream meanwhile (record_stream would do too, but its deferred frees made the allocator grow
+        # and stall erratically: 36 -> 60-110 ms per step in some runs)
+        self.keep.extend(tensors)
         with torch.cuda.stream(self.side):
             self.side.wait_event(ev)
-            for t in tensors:
-                t.record_stream(self.side)        # the caching allocator must not hand these to the main stream meanwhile
             fn()
 
     def join(self):
