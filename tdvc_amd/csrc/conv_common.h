@@ -90,6 +90,28 @@ __device__ __forceinline__ void epilogue4(const ConvParams& p, int n, int oy, in
   }
 }
 
+// XCD-aware tile walk of the persistent kernels (v3, v7).  Workgroups are dispatched round-robin over the 8 XCDs, each
+// with its own L2, so workgroup x of a launch runs on XCD x % 8.  The raster of tiles is cut into 8 contiguous bands,
+// one per XCD, and a workgroup walks its XCD's band with the stride of that XCD's workgroup count: neighbouring tiles
+// (shared halo rows / columns) and consecutive tile rows are fetched through ONE L2 instead of eight.  Needs
+// gridDim.x % 8 == 0 (then x % 8 is the XCD whatever blockIdx.y / z are); otherwise the plain interleaved walk.
+__device__ __forceinline__ void xcd_tile_walk(int ntiles, int& first, int& stride, int& my_tiles) {
+  const int gx = (int)gridDim.x, bx = (int)blockIdx.x;
+  if ((gx & 7) == 0 && ntiles >= gx) {
+    const int xcd = bx & 7, slot = bx >> 3, per = gx >> 3;
+    const int nb = (ntiles + 7) >> 3;                      // tiles per band (the last band may be shorter)
+    const int band0 = xcd * nb;
+    const int band_n = min(nb, ntiles - band0);
+    first = band0 + slot;
+    stride = per;
+    my_tiles = slot < band_n ? (band_n - slot + per - 1) / per : 0;
+  } else {
+    first = bx;
+    stride = gx;
+    my_tiles = (ntiles - first + stride - 1) / stride;
+  }
+}
+
 // Which layers take the transposed epilogue below (everything else uses epilogue4).
 inline bool conv_is_simple(const ConvParams& p) {
   const bool shuf = p.out_mode == TDVC_OUT_SHUFFLE2;

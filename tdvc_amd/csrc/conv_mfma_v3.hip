@@ -51,8 +51,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v3_kernel(const ConvParams p
   const int total_items = TIH * TIW * 4;
   const int ntaps = p.ntaps, nchunks = p.nchunks;
 
-  const int first = blockIdx.x, stride = gridDim.x;
-  const int my_tiles = (e.ntiles - first + stride - 1) / stride;
+  int first, stride, my_tiles;                             // XCD-aware: one contiguous band of tiles per L2
+  convk::xcd_tile_walk(e.ntiles, first, stride, my_tiles);
   const int nstages = my_tiles * nchunks;
   if (nstages <= 0) return;
 

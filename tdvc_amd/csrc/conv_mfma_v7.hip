@@ -75,8 +75,8 @@ __global__ __launch_bounds__(NTHR7, 1) void conv_mfma_v7_kernel(const ConvParams
   const int cb = blockIdx.y, n = blockIdx.z;
   const int nchunks = p.nchunks;
 
-  const int first = blockIdx.x, stride = gridDim.x;
-  const int my_tiles = (e.ntiles - first + stride - 1) / stride;
+  int first, stride, my_tiles;                             // XCD-aware: one contiguous band of tiles per L2
+  convk::xcd_tile_walk(e.ntiles, first, stride, my_tiles);
   const int nstages = my_tiles * nchunks;
   if (nstages <= 0) return;
 
