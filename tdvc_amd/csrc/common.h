@@ -62,6 +62,18 @@ static inline bool fmap_ok32(const tdvc_fmap& f) {
   return f.p && f.dtype == TDVC_F32 && f.sp >= f.C && f.N > 0 && f.H > 0 && f.W > 0 && (((uintptr_t)f.p) & 3) == 0;
 }
 
+// XCD-aware tile index for one-workgroup-per-tile launches: workgroups go round-robin over the 8 XCDs (each with its own
+// L2), so neighbouring blockIdx.x values sit on different L2s.  Workgroup b is given tile (b % 8) * band + b / 8: the
+// tiles an XCD works on are contiguous in the raster and their shared halo lines meet in one L2.  A bijection on
+// [0, gridDim.x); the identity when neither gridDim.x % 8 == 0 nor the grid is one-dimensional (then b % 8 is not the XCD).
+__device__ __forceinline__ int tdvc_xcd_tile(int b) {
+  const int gx = (int)gridDim.x;
+  const bool planar = gridDim.y * gridDim.z == 1;
+  if ((gx & 7) != 0 && !planar) return b;
+  const int q = gx >> 3, r = gx & 7, c = b & 7;
+  return c * q + min(c, r) + (b >> 3);
+}
+
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
   switch (act) {
     case TDVC_ACT_RELU: return v > 0.f ? v : 0.f;

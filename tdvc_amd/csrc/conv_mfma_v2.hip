@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v2_kernel(const ConvParams p
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, r = lane & 31;
-  const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
+  const int tile_id = tdvc_xcd_tile(blockIdx.x);
+  const int tx = tile_id % p.tiles_x, ty = tile_id / p.tiles_x;
   const int cb = blockIdx.y, n = blockIdx.z;
   const int TIW = TW2 + p.kw - 1;
   const int total_items = (TH2 + p.kh - 1) * TIW * CK8;

@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void dcn_fused_kernel(const DcnParams p) {
   const int hh = lane >> 5, r = lane & 31;
   const int mt = wave & 1, nt = wave >> 1;
   const int tiles_x = (p.W + DCN_TPX - 1) / DCN_TPX;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int tile_id = tdvc_xcd_tile(blockIdx.x);
+  const int tx = tile_id % tiles_x, ty = tile_id / tiles_x;
   const int n = blockIdx.y;
   const half_t* xn = p.x + (long)n * p.x_sn;
 
