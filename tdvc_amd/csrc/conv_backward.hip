@@ -91,7 +91,7 @@ constexpr int PSX = WG_CI * 2 + 16;             // ... of the X tile (80)
 struct WgradParams {
   FMap g, x;
   int Ho, Wo, stride, pad;
-  int ntaps_all;                                // taps of the layer; blockIdx.z picks a group of <= WG_MAXT of them
+  int ntaps_all;                                // taps of the layer; a workgroup takes one group of <= WG_MAXT of them
   int8_t tap_dy[TDVC_MAX_TAPS], tap_dx[TDVC_MAX_TAPS];
   int co_tiles, ci_tiles;
   int blocks_x, blocks_y, nblocks;              // pixel blocks per image, total over the batch
@@ -100,6 +100,7 @@ struct WgradParams {
   float* work;                                  // [P][ntaps_all][co_tiles*64][ci_tiles*32]
   float* bwork;                                 // [P][co_tiles*64] column sums of dY (bias gradient), or null
   long long* stamps;                            // diagnostic: per (workgroup, wave) cycles per phase, or null
+  int nworkers, ngroups;                        // launch shape (the grid is one-dimensional and XCD-aware)
 };
 
 typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
@@ -116,9 +117,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   unsigned char* gt = smem;                                         // dY tile: WG_TH*WG_TW pixels x PSG
   unsigned char* xt = smem + WG_TH * WG_TW * PSG;                   // X tile: tih*tiw pixels x PSX
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cit = blockIdx.x % p.ci_tiles, cot = blockIdx.x / p.ci_tiles;
-  const int worker = blockIdx.y, nworkers = gridDim.y;
-  const int tap0 = blockIdx.z * WG_MAXT, ntaps_g = min(WG_MAXT, p.ntaps_all - tap0);      // this workgroup's tap group
+  // XCD-aware one-dimensional grid: workgroup b runs on XCD b % 8; all (dW tile, tap group) workgroups of a worker walk
+  // the same pixel blocks, so they are placed on the same XCD and share the dY / X tiles in one L2.  The j-th workgroup
+  // of XCD c is (worker c + 8 (j / T), item j % T), T = tiles x tap groups; the grid is padded to 8 ceil(workers / 8) T.
+  const int T = p.co_tiles * p.ci_tiles * p.ngroups;
+  const int jx = (int)blockIdx.x >> 3;
+  const int worker = ((int)blockIdx.x & 7) + 8 * (jx / T), nworkers = p.nworkers;
+  if (worker >= nworkers) return;                                   // padding workgroups (whole workgroup, before any barrier)
+  const int item = jx % T, tile = item % (p.co_tiles * p.ci_tiles), zgroup = item / (p.co_tiles * p.ci_tiles);
+  const int cit = tile % p.ci_tiles, cot = tile / p.ci_tiles;
+  const int tap0 = zgroup * WG_MAXT, ntaps_g = min(WG_MAXT, p.ntaps_all - tap0);         // this workgroup's tap group
   const int co0 = cot * WG_CO, ci0 = cit * WG_CI;
 
   // taps of this wave: wave, wave + 4, wave + 8 (inside the launch's group)
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   const unsigned char* abase = gt + (8 * khalf + rq) * PSG + colbase * 2;
   const unsigned char* bbase = xt + (8 * khalf + rq) * p.stride * PSX + colbase * 2;
   // bias gradient rides along: the workgroups of input-channel tile 0 / tap group 0 also sum their dY tiles per channel
-  const bool do_bias = p.bwork != nullptr && cit == 0 && blockIdx.z == 0;
+  const bool do_bias = p.bwork != nullptr && cit == 0 && zgroup == 0;
   float bs[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) bs[q] = 0.f;
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   }
   if (p.stamps && lane == 0) {
     mark(5);
-    long long* o = p.stamps + (((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    long long* o = p.stamps + (((long)(zgroup * nworkers + worker) * (p.co_tiles * p.ci_tiles) + tile) * 4 + wave) * 8;
     for (int k = 0; k < 6; ++k) o[k] = ph[k];
   }
 }
@@ -451,6 +459,7 @@ extern "C" int tdvc_conv_wgrad_bias(const tdvc_fmap* g, const tdvc_fmap* x, int 
   p.square_x = square_x;
   const int groups = (ntaps + WG_MAXT - 1) / WG_MAXT;
   const int workers = wgrad_workers(p.co_tiles, p.ci_tiles, groups, p.nblocks, ntaps);
+  p.nworkers = workers; p.ngroups = groups;
   p.bwork = db ? work + (long)workers * p.co_tiles * WG_CO * p.ci_tiles * WG_CI * ntaps : nullptr;
   p.stamps = (g_wg_stamp && (long)p.co_tiles * p.ci_tiles * workers * groups <= g_wg_stamp_cap) ? g_wg_stamp : nullptr;
   const int xl = (p.tih * p.tiw * (WG_CI / 8) + 255) / 256;
@@ -459,7 +468,7 @@ extern "C" int tdvc_conv_wgrad_bias(const tdvc_fmap* g, const tdvc_fmap* x, int 
   auto go = [&](auto kern) -> int {
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err != hipSuccess) { tdvc_set_error("tdvc_conv_wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(err)); return (int)err; }
-    hipLaunchKernelGGL(kern, dim3(p.co_tiles * p.ci_tiles, workers, groups), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(8 * ((workers + 7) / 8) * p.co_tiles * p.ci_tiles * groups)), dim3(256), lds, st, p);
     return 0;
   };
   const int rc = xl <= 6 ? go(&conv_wgrad_kernel<6>) : (xl <= 9 ? go(&conv_wgrad_kernel<9>) : go(&conv_wgrad_kernel<18>));
