@@ -469,3 +469,30 @@ def test_train_step_graph_replay_matches_eager(report):
         assert abs(a["bpp_res"] - b["bpp_res"]) <= 0.02 * a["bpp_res"] and abs(a["bpp_mv"] - b["bpp_mv"]) <= 0.05 * a["bpp_mv"]
     report("train step, eager vs graph replay: " + "; ".join(f"{a['rd_loss']:.3f}/{b['rd_loss']:.3f}" for a, b in zip(logs[False], logs[True])))
     assert logs[True][-1]["rd_loss"] < logs[True][0]["rd_loss"]
+
+
+def test_train_step_overflow_policy(report):
+    """GradScaler's policy (tools/train.py:101,146-149): a loss scale that overflows the fp16 activation gradients gives a
+    non-finite gradient norm -> the step is skipped (parameters untouched) and the scale halves until steps go through"""
+    from tdvc_amd import synth
+    from tdvc_amd.model.pnet import VideoCompressor
+    from tdvc_amd.train import TrainStep
+    gop = synth.make_gop(99, 7, 64, 64).float()
+    x = gop[3:4].cuda()
+    refs = torch.stack([gop[0], gop[0], gop[1], gop[2]]).unsqueeze(0).cuda()
+    m = VideoCompressor()
+    synth.fill_parameters(m)
+    m = m.cuda()
+    step = TrainStep(m, train_lambda=2048.0, lr=1e-4, loss_scale=2.0 ** 30)
+    before = torch.cat([p.detach().reshape(-1).clone() for p in step.main_params])
+    first = step(x, refs)
+    after = torch.cat([p.detach().reshape(-1) for p in step.main_params])
+    assert first["skipped"] and first["loss_scale"] == 2.0 ** 29 and torch.equal(before, after)
+    logs = [first]
+    for _ in range(40):
+        logs.append(step(x, refs))
+        if not logs[-1]["skipped"]:
+            break
+    assert not logs[-1]["skipped"] and logs[-1]["grad_norm"] == logs[-1]["grad_norm"]
+    assert not torch.equal(before, torch.cat([p.detach().reshape(-1) for p in step.main_params]))
+    report(f"overflow policy: {sum(l['skipped'] for l in logs)} skipped steps, loss scale 2^30 -> {logs[-1]['loss_scale']:.0f}, then rd_loss {logs[-1]['rd_loss']:.3f}")
