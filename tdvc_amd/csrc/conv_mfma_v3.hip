@@ -135,7 +135,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v3_kernel(const ConvParams p
     ST3(4);
 
     // ---- matrix phase: LDS only ----------------------------------------------------------------
+    // space-to-depth view of a 3x3 stride-2 conv: virtual tap (dy, dx) of parity block (py, px) is original tap
+    // (2dy + py - 1, 2dx + px - 1); 7 of the 16 (tap, parity) blocks fall outside the 3x3 window and hold zero weights:
+    // skipped (wave-uniform), 9/16 of the MFMAs remain
+    unsigned tapmask = ~0u;
+    if (p.s2d) {
+      const int q = (ch * CK3) / p.Corig, py = q >> 1, px = q & 1;
+      tapmask = 0u;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if ((py == 1 || (t >> 1) == 1) && (px == 1 || (t & 1) == 1)) tapmask |= 1u << t;
+    }
     for (int t = 0; t < ntaps; ++t) {
+      if (!((tapmask >> t) & 1u)) continue;
       const unsigned char* wslot = wlds + t * WSL + lane * 16;
       const int toff = tapoff[t];
 #pragma unroll

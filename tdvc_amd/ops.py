@@ -151,9 +151,10 @@ class PackedConv:
             self.bias[:self.cout] = b[torch.from_numpy(convpack.shuffle_perm(self.cout)).to(b.device)] if self.shuffle else b
         if self.dgrad is not None:
             self.dgrad.repack()
-        aux = self.__dict__.get("_colpc")          # the DCN weight seen as a 1x1 conv over sampled columns (backward only)
-        if aux is not None:
-            aux.repack()
+        for key in ("_colpc", "_plain"):           # the DCN weight as a 1x1 conv over sampled columns; the plain stride-2 form
+            aux = self.__dict__.get(key)
+            if aux is not None:
+                aux.repack()
 
 
 def _cout_pad(cout):
@@ -217,6 +218,7 @@ class PackBatch:
             self.pcs.append(pc)
             walk(pc.dgrad)
             walk(pc.__dict__.get("_colpc"))
+            walk(pc.__dict__.get("_plain"))
         for pc in pcs:
             walk(pc)
         self._build()
@@ -321,10 +323,25 @@ def pack_conv(weight: torch.Tensor, bias: torch.Tensor | None, stride=1, pad=0, 
     return pc
 
 
+SMALL_MAP_PIXELS = 8192      # conv_mfma_v9's range (csrc/conv_mfma_v9.hip)
+
+
+def _plain_form(pc: PackedConv) -> PackedConv:
+    """the un-transformed stride-2 3x3 packing of a layer whose main form is the space-to-depth view (built on first use)"""
+    alt = pc.__dict__.get("_plain")
+    if alt is None:
+        alt = pack_conv(pc.wsrc, pc.bsrc, stride=2, pad=1, allow_s2d=False, layout=pc.layout, param_w=pc.param_w, param_b=pc.param_b)
+        pc.__dict__["_plain"] = alt
+    return alt
+
+
 def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, res: FM | None = None,
          res2: FM | None = None, gdn=GDN_NONE, aux: FM | None = None, square=False, out_dtype=torch.float16,
          round16=False, nchw_out: torch.Tensor | None = None) -> FM | torch.Tensor:
     assert x.C == pc.cin, f"conv: input has {x.C} channels, layer packed for {pc.cin}"
+    rec_pc = pc                                   # the tape records the layer itself (its dgrad / wgrad forms hang off it)
+    if pc.s2d and x.N * (x.H // 2) * (x.W // 2) <= SMALL_MAP_PIXELS:
+        pc = _plain_form(pc)                      # small maps: the plain stride-2 form runs on the split-K kernel
     if pc.s2d:
         if x.H % 2 or x.W % 2:
             raise L.TdvcHipError("conv: the space-to-depth stride-2 path needs even H, W")
@@ -374,10 +391,10 @@ def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, 
                             flops=2.0 * x.N * Ho * Wo * pc.cout * x.C * len(pc.taps),
                             flops_real=(x.N * Ho * Wo * pc.flops_per_px) if pc.s2d else 2.0 * x.N * Ho * Wo * pc.cout * pc.cin_real * len(pc.taps),
                             bytes=2.0 * x.N * (x.H * x.W * x.C + Ho * Wo * pc.cout * (4 if pc.shuffle else 1) / (4 if pc.shuffle else 1))))
-        _rec("conv", x, pc, None if nchw_out is not None else ret, act, slope, res, res2, gdn, aux, square, nchw_out)
+        _rec("conv", x, rec_pc, None if nchw_out is not None else ret, act, slope, res, res2, gdn, aux, square, nchw_out)
         return ret
     L.check(L.lib().tdvc_conv2d(C.byref(d), _stream()), "conv2d")
-    _rec("conv", x, pc, None if nchw_out is not None else ret, act, slope, res, res2, gdn, aux, square, nchw_out)
+    _rec("conv", x, rec_pc, None if nchw_out is not None else ret, act, slope, res, res2, gdn, aux, square, nchw_out)
     return ret
 
 

@@ -37,6 +37,7 @@ CASES = [
     ("3x3_64_64_big", 2, 64, 64, 3, 1, 1, 70, 100),
     ("3x3_s2_64_128", 1, 64, 128, 3, 2, 1, 32, 48),
     ("3x3_s2_odd", 1, 128, 128, 3, 2, 1, 18, 30),
+    ("3x3_s2_64_128_large", 1, 64, 128, 3, 2, 1, 192, 256),     # > 8192 output pixels: the space-to-depth form (v3)
     ("1x1_128_64", 1, 128, 64, 1, 1, 0, 20, 36),
     ("1x1_s2_64_128", 1, 64, 128, 1, 2, 0, 32, 64),
     ("1x1_256_64", 1, 256, 64, 1, 1, 0, 16, 40),
