@@ -106,16 +106,21 @@ __global__ __launch_bounds__(NW9 * 64) void conv_mfma_v9_kernel(const ConvParams
 }  // namespace
 
 static bool g_v9_enabled = true;
+static long g_v9_work_limit = 1L << 20;      // pixels x output channels above which a v3-eligible layer stays on v3
+extern "C" void tdvc_debug_set_conv_v9_work_limit(long v) { g_v9_work_limit = v; }
 // tests switch the small-map kernel off to keep exercising the tiled kernels on small shapes
 extern "C" void tdvc_debug_enable_conv_v9(int enable) { g_v9_enabled = enable != 0; }
 
-bool conv_v9_eligible(const tdvc_conv_desc* d, int Ho, int Wo) {
+bool conv_v9_eligible(const tdvc_conv_desc* d, int Ho, int Wo, bool v3_ok) {
   static const bool off = getenv("TDVC_CONV_NO_V9") != nullptr || getenv("TDVC_CONV_V1") != nullptr;
   if (off || !g_v9_enabled || d->s2d) return false;
   const long px = (long)Ho * Wo * d->x.N;
   static const long maxpx = getenv("TDVC_V9_MAX_PX") ? atol(getenv("TDVC_V9_MAX_PX")) : 8192;
   static const long minpx = getenv("TDVC_V9_MIN_PX") ? atol(getenv("TDVC_V9_MIN_PX")) : 0;
   const long ksteps = (long)((d->x.C + d->ck - 1) / d->ck) * ((d->ntaps * (d->ck / 8) + 1) / 2);
+  // every 32-channel output tile gathers its own activation fragments: with many output channels on the larger maps the
+  // stage-pipelined kernel (one staged tile for 64 output channels) wins again (3x3 128->512 at 68x120: 31 vs 72 us)
+  if (v3_ok && px * d->cout > g_v9_work_limit) return false;
   return px <= maxpx && px >= minpx && ksteps >= 4 && (d->x.C % 8) == 0;
 }
 
