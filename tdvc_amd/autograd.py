@@ -21,6 +21,36 @@ from . import ops
 from .ops import FM
 
 
+class MirrorPool:
+    """Zeroed gradient-mirror buffers that outlive a step.  A tape takes its mirrors from the pool instead of
+    `torch.zeros_like` (211 fills, 1.5 ms of a 35 ms step); after the sweep `recycle()` re-zeroes the used ones on the
+    side stream, where the fills run under the optimizer and the next forward instead of on the backward's critical
+    path.  ~5 GB stay allocated at 4 x 256 x 256 (of 288 GB)."""
+
+    def __init__(self):
+        self.free: dict = {}
+        self.used: list = []
+
+    def get(self, like: torch.Tensor) -> torch.Tensor:
+        key = (tuple(like.shape), like.dtype, like.device)
+        lst = self.free.get(key)
+        t = lst.pop() if lst else torch.zeros_like(like)
+        self.used.append((key, t))
+        return t
+
+    def recycle(self, side):
+        """everything issued so far (main and side stream) precedes the fills; the next step waits for `side`"""
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            for key, t in self.used:
+                t.zero_()
+                self.free.setdefault(key, []).append(t)
+        self.used = []
+
+
 class Tape:
     def __init__(self, loss_scale: float = 1.0):
         self.nodes: list = []
@@ -38,13 +68,14 @@ class Tape:
         # weight / bias gradients are off the critical path of the sweep (nothing in the backward reads them): with a side
         # stream they run next to the dgrad chain and fill the CUs the small layers leave idle
         self.side = None
+        self.pool: MirrorPool | None = None       # persistent zeroed mirrors (TrainStep, eager mode)
 
     # ------------------------------------------------------------------ gradient views
     def _base(self, t: torch.Tensor) -> torch.Tensor:
         key = t.data_ptr()
         g = self.gbuf.get(key)
         if g is None:
-            g = torch.zeros_like(t)
+            g = self.pool.get(t) if self.pool is not None else torch.zeros_like(t)
             self.gbuf[key] = g
             self.keep.append(t)
         return g
@@ -123,9 +154,10 @@ def param_grad(p: torch.Tensor) -> torch.Tensor:
 
 
 @contextlib.contextmanager
-def record(loss_scale: float = 1.0, side_stream=None):
+def record(loss_scale: float = 1.0, side_stream=None, pool: MirrorPool | None = None):
     tape = Tape(loss_scale)
     tape.side = side_stream
+    tape.pool = pool
     prev, ops.TAPE = ops.TAPE, tape
     try:
         yield tape

@@ -128,6 +128,8 @@ class TrainStep:
         self._ready, self._n_nodes = None, None      # gradient-completion order, learnt on step 0
         # weight-gradient kernels run on a side stream next to the dgrad chain (autograd.Tape.off_path)
         self._side = torch.cuda.Stream() if (side_stream and torch.cuda.is_available()) else None
+        self._pool = autograd.MirrorPool()            # zeroed gradient mirrors, re-zeroed off the critical path
+        self.use_pool = True
         self.lam = float(train_lambda)
         self.loss_scale = float(loss_scale)
         self.clip = float(clip)
@@ -152,7 +154,10 @@ class TrainStep:
         """forward, loss seeds, backward: gradients accumulate into the (zeroed) buckets"""
         B, _, H, W = input_image.shape
         self.buckets.zero()
-        with autograd.record(self.loss_scale, side_stream=self._side) as tape:
+        pool = self._pool if (self.use_pool and self._side is not None and not capturing) else None
+        if pool is not None:
+            torch.cuda.current_stream().wait_stream(self._side)          # last step's re-zeroing of the mirrors
+        with autograd.record(self.loss_scale, side_stream=self._side, pool=pool) as tape:
             if self._ready is None:
                 tape.touch_log = {}                                  # first step: learn when each gradient is final
             elif not capturing:
@@ -164,6 +169,8 @@ class TrainStep:
             tape.grad_tensor(recon).copy_(diff * (2.0 * self.lam * self.loss_scale / diff.numel()))
             tape.rate_grad = 1.0 / float(B * H * W)
             tape.backward()
+        if pool is not None:
+            pool.recycle(self._side)
         if self._ready is None:
             self._ready, self._n_nodes = tape.touch_log, tape.n_backward_nodes
             self.buckets.reorder(self._ready, self._n_nodes)
