@@ -409,13 +409,18 @@ static long long* g_wg_stamp = nullptr;
 static long g_wg_stamp_cap = 0;
 extern "C" void tdvc_debug_set_stamp_buffer_wgrad(void* buf, int cap_workgroups) { g_wg_stamp = (long long*)buf; g_wg_stamp_cap = cap_workgroups; }
 
+static int g_wg_max_workers = 256;
+static long g_wg_partial_cap = 16L << 20;
+extern "C" void tdvc_debug_set_wgrad_max_workers(int n) { g_wg_max_workers = n < 1 ? 1 : n; }
+extern "C" void tdvc_debug_set_wgrad_partial_cap_mb(int mb) { g_wg_partial_cap = (long)(mb < 1 ? 1 : mb) << 20; }
+
 static int wgrad_workers(int co_tiles, int ci_tiles, int groups, int nblocks, int ntaps) {
   int w = 1024 / (co_tiles * ci_tiles * groups);      // ~4 workgroups per CU over the whole launch
   const long dw_bytes = (long)co_tiles * WG_CO * ci_tiles * WG_CI * ntaps * 4;
-  const long cap = (16L << 20) / dw_bytes;            // partial sums are written and re-read once: keep them <= 16 MB per layer
+  const long cap = g_wg_partial_cap / dw_bytes;            // partial sums are written and re-read once: keep them <= 16 MB per layer
   if (w > cap) w = (int)cap;
   if (w > nblocks) w = nblocks;
-  if (w > 256) w = 256;
+  if (w > g_wg_max_workers) w = g_wg_max_workers;
   if (w < 1) w = 1;
   return w;
 }

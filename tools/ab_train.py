@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """A/B inside ONE process (box-to-box and run-to-run noise is larger than the effects measured here): median step time
-of TrainStep with an attribute toggled.  python tools/ab_train.py attr value_a value_b"""
+of TrainStep with an attribute toggled.  python tools/ab_train.py attr value_a value_b
+or with two statements (names in scope: step, lib, torch):  python tools/ab_train.py exec "stmt_a" "stmt_b" """
 import os
 import statistics
 import sys
@@ -13,7 +14,10 @@ from tdvc_amd.model import VideoCompressor  # noqa: E402
 from tdvc_amd.synth import fill_parameters, make_gop, ref_list  # noqa: E402
 from tdvc_amd.train import TrainStep  # noqa: E402
 
-attr, va, vb = sys.argv[1], eval(sys.argv[2]), eval(sys.argv[3])
+attr = sys.argv[1]
+va, vb = (sys.argv[2], sys.argv[3]) if attr == "exec" else (eval(sys.argv[2]), eval(sys.argv[3]))
+from tdvc_amd import _lib  # noqa: E402
+lib = _lib.lib()
 torch.manual_seed(0)
 m = VideoCompressor(); fill_parameters(m); m = m.cuda().train()
 xs, rs = [], []
@@ -27,7 +31,10 @@ for _ in range(5):
 res = {repr(va): [], repr(vb): []}
 for rnd in range(4):
     for v in (va, vb):
-        setattr(step, attr, v)
+        if attr == "exec":
+            exec(v)
+        else:
+            setattr(step, attr, v)
         for _ in range(3):
             step(x, refs)
         torch.cuda.synchronize()
