@@ -259,6 +259,16 @@ int tdvc_ar_quantize(const tdvc_fmap* y, const tdvc_fmap* gp, const int32_t* pos
 /* indexes only (decoder: needed before the symbols can be read from the stream). */
 int tdvc_ar_indexes(const tdvc_fmap* gp, const int32_t* pos, int npos, const float* scale_table, int ntable,
                     int M, int W, int32_t* indexes, void* stream);
+/* The decoder's whole context loop for ONE image, natively: positions pos_table[0 .. npos_total) in raster (stream)
+ * order, per position tdvc_ar_gather -> convs[0 .. nconvs) (the caller's descriptors: context conv over x1 into pc,
+ * entropy_parameters into gp; fixed buffers) -> tdvc_ar_indexes -> host range decoder on `data` (tables as in
+ * tdvc_rans_decode, HOST memory) -> tdvc_ar_quantize.  idx_dev / sym_dev: device int32 [H][W][M]; y_hat is filled.
+ * Synchronises the stream once per position (the stream order of compressai's bitstream leaves no other choice). */
+int tdvc_ar_decode_serial(const uint8_t* data, int64_t nbytes, const int32_t* cdfs, int32_t cdf_stride, const int32_t* cdf_sizes,
+                          const int32_t* offsets, const tdvc_fmap* y_hat, const tdvc_fmap* params, const tdvc_fmap* x1,
+                          const tdvc_fmap* pc, const tdvc_conv_desc* convs, int nconvs, const tdvc_fmap* gp,
+                          const int32_t* pos_table, int npos_total, int M, int W, const float* scale_table, int ntable,
+                          int32_t* idx_dev, int32_t* sym_dev, void* stream);
 /* q[n][h][w][c] = round(z - median[c]) as int32 in the fmap's own order (factorised-prior symbols). */
 int tdvc_round_symbols(const tdvc_fmap* z, const float* median, int32_t* out, void* stream);
 

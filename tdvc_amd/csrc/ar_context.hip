@@ -119,3 +119,47 @@ extern "C" int tdvc_round_symbols(const tdvc_fmap* z, const float* median, int32
   hipLaunchKernelGGL(round_symbols_kernel, g1((long)z->N * z->H * z->W * z->C), dim3(256), 0, ST(stream), to_dev(*z), median, out);
   return tdvc_launch_status("tdvc_round_symbols");
 }
+
+// The decoder's context loop in native code.  The y stream is in raster order (compressai's bitstream), and position
+// (h, w) needs y_hat(h, w - 1): 8160 strictly serial steps per coder at 1080p.  Per step: gather -> context conv ->
+// entropy_parameters (the caller's conv descriptors, fixed buffers) -> CDF indexes -> host range decoder -> quantise.
+// Driving this from Python cost ~230 us per position (3.7 s per 1080p frame); here a step is seven enqueues, one
+// 512-byte device->host copy + stream wait, the host decoder and one host->device copy.
+extern "C" int tdvc_ar_decode_serial(const uint8_t* data, int64_t nbytes, const int32_t* cdfs, int32_t cdf_stride, const int32_t* cdf_sizes,
+                                     const int32_t* offsets, const tdvc_fmap* y_hat, const tdvc_fmap* params, const tdvc_fmap* x1,
+                                     const tdvc_fmap* pc, const tdvc_conv_desc* convs, int nconvs, const tdvc_fmap* gp,
+                                     const int32_t* pos_table, int npos_total, int M, int W, const float* scale_table, int ntable,
+                                     int32_t* idx_dev, int32_t* sym_dev, void* stream) {
+  TDVC_CHECK(data && cdfs && cdf_sizes && offsets && y_hat && params && x1 && pc && convs && gp && pos_table && scale_table && idx_dev && sym_dev,
+             "tdvc_ar_decode_serial: null argument");
+  TDVC_CHECK(nconvs >= 1 && nconvs <= 8 && npos_total >= 1 && M >= 1 && M <= 4096 && W >= 1, "tdvc_ar_decode_serial: bad sizes");
+  void* dec = tdvc_rans_decoder_create(data, nbytes);
+  if (!dec) return TDVC_EINVAL;
+  int32_t* host = nullptr;                                // [2][M] indexes | symbols, pinned
+  hipError_t err = hipHostMalloc(reinterpret_cast<void**>(&host), sizeof(int32_t) * 2 * (size_t)M, hipHostMallocDefault);
+  if (err != hipSuccess) { tdvc_rans_decoder_destroy(dec); tdvc_set_error("tdvc_ar_decode_serial: hipHostMalloc failed: %s", hipGetErrorString(err)); return (int)err; }
+  hipStream_t st = ST(stream);
+  int rc = TDVC_OK;
+  for (int k = 0; k < npos_total && rc == TDVC_OK; ++k) {
+    const int32_t* pos = pos_table + 2 * (long)k;
+    rc = tdvc_ar_gather(y_hat, params, pos, 1, x1, pc, stream);
+    for (int c = 0; c < nconvs && rc == TDVC_OK; ++c) rc = tdvc_conv2d(&convs[c], stream);
+    if (rc == TDVC_OK) rc = tdvc_ar_indexes(gp, pos, 1, scale_table, ntable, M, W, idx_dev, stream);
+    if (rc != TDVC_OK) break;
+    int32_t* idx_k = idx_dev + (long)k * M;               // raster order: position k = h * W + w owns [k*M, (k+1)*M)
+    int32_t* sym_k = sym_dev + (long)k * M;
+    err = hipMemcpyAsync(host, idx_k, sizeof(int32_t) * M, hipMemcpyDeviceToHost, st);
+    if (err == hipSuccess) err = hipStreamSynchronize(st);
+    if (err != hipSuccess) { tdvc_set_error("tdvc_ar_decode_serial: copy / sync failed: %s", hipGetErrorString(err)); rc = (int)err; break; }
+    rc = tdvc_rans_decoder_decode(dec, host, M, cdfs, cdf_stride, cdf_sizes, offsets, host + M);
+    if (rc != TDVC_OK) break;
+    err = hipMemcpyAsync(sym_k, host + M, sizeof(int32_t) * M, hipMemcpyHostToDevice, st);
+    if (err != hipSuccess) { tdvc_set_error("tdvc_ar_decode_serial: upload failed: %s", hipGetErrorString(err)); rc = (int)err; break; }
+    // the next iteration's stream wait orders this upload before `host` is written again
+    rc = tdvc_ar_quantize(nullptr, gp, pos, 1, scale_table, ntable, sym_dev, y_hat, sym_dev, idx_dev, stream);
+  }
+  (void)hipStreamSynchronize(st);
+  (void)hipHostFree(host);
+  tdvc_rans_decoder_destroy(dec);
+  return rc;
+}

@@ -505,18 +505,22 @@ class Cheng2020Anchor(nn.Module, PackCache):
         y_hat_all = FM.zeros(B, H, W, M, device=dev)
         sym = torch.zeros((H, W, M), dtype=torch.int32, device=dev)
         idx = torch.zeros((H, W, M), dtype=torch.int32, device=dev)
+        # the per-position chain as fixed conv descriptors over fixed buffers: context conv (1x1 over the gathered
+        # neighbourhood) into pc[2M:4M], entropy_parameters into gp; the loop itself runs natively
+        # (tdvc_ar_decode_serial: Python drove it at ~230 us per position)
+        e = self.entropy_parameters
+        v = lambda fm, c0, C_: FM(fm.t, c0, 1, C_)
+        d0, _, _, _, _, _ = ops.conv_desc(v(x1, 0, x1.C), self._ctx_1x1(), out=v(pc, 2 * M, 2 * M))
+        t0 = FM.empty(1, 1, 1, ops.pad8(e[0].out_channels), device=dev)
+        t1 = FM.empty(1, 1, 1, ops.pad8(e[2].out_channels), device=dev)
+        gp = FM.empty(1, 1, 1, 2 * M, dtype=torch.float32, device=dev)
+        d1, _, _, _, _, _ = ops.conv_desc(v(pc, 0, 4 * M), pk_conv(self, "ep0", e[0]), out=t0, **LR)
+        d2, _, _, _, _, _ = ops.conv_desc(t0, pk_conv(self, "ep2", e[2]), out=t1, **LR)
+        d3, _, _, _, _, _ = ops.conv_desc(t1, pk_conv(self, "ep4", e[4]), out=gp, out_dtype=torch.float32)
+        pos_table = torch.tensor([[h, w] for h in range(H) for w in range(W)], dtype=torch.int32, device=dev)
         for b in range(B):
-            dec = ops.RansDecoder(strings[0][b])
-            y_hat = y_hat_all.batch(b, 1)
-            for h in range(H):
-                for w in range(W):
-                    pos = torch.tensor([[h, w]], dtype=torch.int32, device=dev)
-                    gp = self._ar_step(y_hat, params.batch(b, 1), pos, 1, x1, pc)
-                    ops.ar_indexes(gp, pos, 1, table, M, W, idx)
-                    q = dec.decode(idx[h, w].cpu().numpy(), gct)
-                    sym[h, w] = torch.from_numpy(q).to(dev)
-                    ops.ar_quantize(None, gp, pos, 1, table, y_hat, sym, idx, symbols_in=sym)
-            dec.close()
+            ops.ar_decode_serial(strings[0][b], gct, y_hat_all.batch(b, 1), params.batch(b, 1), x1, pc, [d0, d1, d2, d3], gp, pos_table,
+                                 M, W, table, idx, sym)
         return {"x_hat": self.run_g_s(y_hat_all) if synth else None, "y_hat": y_hat_all}
 
 

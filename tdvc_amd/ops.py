@@ -335,9 +335,11 @@ def _plain_form(pc: PackedConv) -> PackedConv:
     return alt
 
 
-def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, res: FM | None = None,
-         res2: FM | None = None, gdn=GDN_NONE, aux: FM | None = None, square=False, out_dtype=torch.float16,
-         round16=False, nchw_out: torch.Tensor | None = None) -> FM | torch.Tensor:
+def conv_desc(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, res: FM | None = None,
+              res2: FM | None = None, gdn=GDN_NONE, aux: FM | None = None, square=False, out_dtype=torch.float16,
+              round16=False, nchw_out: torch.Tensor | None = None):
+    """the `tdvc_conv_desc` a conv() call would launch, without launching it (native loops re-launch fixed descriptors:
+    `tdvc_ar_decode_serial`).  -> (descriptor, result FM / tensor, Ho, Wo, layer form used, layer as recorded)"""
     assert x.C == pc.cin, f"conv: input has {x.C} channels, layer packed for {pc.cin}"
     rec_pc = pc                                   # the tape records the layer itself (its dgrad / wgrad forms hang off it)
     if pc.s2d and x.N * (x.H // 2) * (x.W // 2) <= SMALL_MAP_PIXELS:
@@ -380,6 +382,13 @@ def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, 
                                dtype=out_dtype, device=x.t.device)
         d.y = out.desc()
         ret = out
+    return d, ret, Ho, Wo, pc, rec_pc
+
+
+def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, res: FM | None = None,
+         res2: FM | None = None, gdn=GDN_NONE, aux: FM | None = None, square=False, out_dtype=torch.float16,
+         round16=False, nchw_out: torch.Tensor | None = None) -> FM | torch.Tensor:
+    d, ret, Ho, Wo, pc, rec_pc = conv_desc(x, pc, out, act, slope, res, res2, gdn, aux, square, out_dtype, round16, nchw_out)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -847,6 +856,18 @@ class RansDecoder:
 
     def __del__(self):
         self.close()
+
+
+def ar_decode_serial(data: bytes, t: CdfTables, y_hat: FM, params: FM, x1: FM, pc: FM, descs: list, gp: FM, pos_table: torch.Tensor,
+                     M: int, W: int, scale_table: torch.Tensor, idx: torch.Tensor, sym: torch.Tensor) -> None:
+    """the decoder's serial context loop of one image (`tdvc_ar_decode_serial`); fills y_hat, sym, idx"""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    arr = (L.ConvDesc * len(descs))(*descs)
+    dy, dp, dx, dc, dg = y_hat.desc(), params.desc(), x1.desc(), pc.desc(), gp.desc()
+    L.check(L.lib().tdvc_ar_decode_serial(buf.ctypes.data, buf.size, t.cdf.ctypes.data, t.stride, t.sizes.ctypes.data, t.offsets.ctypes.data,
+                                          C.byref(dy), C.byref(dp), C.byref(dx), C.byref(dc), arr, len(descs), C.byref(dg),
+                                          pos_table.data_ptr(), pos_table.shape[0], M, W, scale_table.data_ptr(), scale_table.numel(),
+                                          idx.data_ptr(), sym.data_ptr(), _stream()), "ar_decode_serial")
 
 
 def ar_gather(y_hat: FM, params: FM, pos: torch.Tensor, npos: int, x1: FM, pc: FM):
