@@ -111,6 +111,16 @@ class Tape:
             self.side.wait_event(ev)
             fn()
 
+    def release(self):
+        """drop every reference the tape holds (closures, mirrors, kept operands, hooks): the hook closures refer back to
+        the tape, so without this a finished tape — and the ~4 GB of activations it pins — waits for the cyclic GC"""
+        self.nodes.clear()
+        self.gbuf.clear()
+        self.keep.clear()
+        self.on_node_done = None
+        self.touch_log = None
+        self.pool = None
+
     def join(self):
         """the main stream waits for the parameter-gradient kernels (before an all-reduce, the optimizer, the tape's end)"""
         if self.side is not None:

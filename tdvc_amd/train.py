@@ -174,6 +174,7 @@ class TrainStep:
         if self._ready is None:
             self._ready, self._n_nodes = tape.touch_log, tape.n_backward_nodes
             self.buckets.reorder(self._ready, self._n_nodes)
+        tape.release()
         # MSE itself is reduced by the caller, outside a captured graph: torch's multi-block reduction zeroes its
         # semaphores with a memset node, and on this ROCm build the first replay after other work on the stream returned
         # partial sums (tools/graph_reduce_repro.py); the gradients never depended on that scalar
