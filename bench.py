@@ -1,19 +1,23 @@
 #!/usr/bin/env python
 """bench.py — 1080p P-frames/s of the MI355X-native TDVC encode/reconstruct path.
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched under
-torch.distributed.run (one rank per GPU).  A *step* is one P-frame through
-`VideoCompressor.forward` (eval mode: both coders' analysis + entropy model rate + synthesis,
-motion compensation, fusion, in-loop filter) at 1088x1920 (1080p padded to x64), batch 1, coded
-in GOP order with the reference-list rule of tools/predict.py:55-62 (closed loop on the GPU's own
-reconstructions).  Inputs are resident in HBM before the timed region.  Ranks code independent
-GOPs (GOP sharding, no collective on the data path): weak scaling.
+Contract: `python bench.py --gpus N --steps K --warmup W`.  For N > 1 it runs one rank per GPU under
+torch.distributed.run; started WITHOUT a launcher (`python bench.py --gpus 8`) it starts the ranks itself as fresh
+child processes before touching the GPU.  A *step* is one P-frame through `VideoCompressor.forward` (eval mode: both
+coders' analysis + entropy-model rate + synthesis, motion compensation, fusion, in-loop filter) at 1088x1920 (1080p
+padded to x64), batch 1, coded in GOP order with the reference-list rule of tools/predict.py:55-62 (closed loop on the
+GPU's own reconstructions).  "Encode" is the reference's own notion (tools/predict.py never passes `is_compress`): the
+forward pass with ESTIMATED bits; the real range-coded encode / decode (`VideoCompressor.encode / decode`) is timed by
+tools/time_codec.py and reported in DESIGN.md.  Inputs are resident in HBM before the timed region.  Ranks code
+independent GOPs (GOP sharding, no collective on the data path): weak scaling.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md §measurement for every field).
+Prints ONE JSON line on rank 0 (see DESIGN.md §6 for every field).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,7 +28,24 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_PX = 7_664_102            # 2 x 3 832 051 MAC per padded pixel, one P-frame forward
 MFMA_F16_PEAK = 2.5e15             # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12                  # HBM3E peak, MI355X_MICROARCH.md (~6.3e12 achievable)
 HP, WP = 1088, 1920
+PMC_FILE = "profiles/r02_conv3x3_64_64_1080p_pmc.txt"
+
+
+def self_launch(argv, n):
+    """`python bench.py --gpus N` without a launcher (how the driver may call it): start the N ranks as fresh child
+    processes under torch.distributed.run BEFORE this process has touched the GPU (a GPU-initialised process is never
+    exec'ed or forked), relay their output, return the launcher's exit code."""
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print("[bench] launching: " + " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
 
 
 def build_model(dev):
@@ -46,23 +67,23 @@ def make_inputs(seed, dev):
 class GopRunner:
     """codes P-frames 1..6 of a 7-frame GOP in order, then starts over"""
 
-    def __init__(self, model, gop):
-        self.m, self.g, self.t, self.refs = model, gop, 0, None
+    def __init__(self, model, gop, enabled_amp=True):
+        self.m, self.g, self.t, self.refs, self.amp = model, gop, 0, None, enabled_amp
 
     def step(self):
         from tdvc_amd.synth import ref_list
         if self.t == 0:
             self.refs = [self.g[0:1]]
         self.t += 1
-        recon, bpp_res, bpp_mv = self.m(self.g[self.t:self.t + 1], ref_list(self.refs), True)
+        recon, bpp_res, bpp_mv = self.m(self.g[self.t:self.t + 1], ref_list(self.refs), self.amp)
         self.refs.append(recon)
         if self.t == 6:
             self.t = 0
         return recon, bpp_res, bpp_mv
 
 
-def cpu_baseline(sample_hw=(512, 960)):
-    """the CPU oracle (fp32 PyTorch restatement) timed on this box's host cores on a bounded sample"""
+def cpu_baseline(sample_hw=(HP, WP)):
+    """the CPU oracle (fp32 PyTorch restatement) timed on this box's host cores: ONE real 1088x1920 P-frame"""
     from oracle.tdvc_ref import VideoCompressor as Ref
     from tdvc_amd.synth import fill_parameters, make_gop, ref_list
     try:
@@ -74,25 +95,32 @@ def cpu_baseline(sample_hw=(512, 960)):
     ref = Ref().eval()
     fill_parameters(ref)
     h, w = sample_hw
-    g = make_gop(1234, 2, h, w)
+    full = (h, w) == (HP, WP)
+    if full:
+        import torch.nn.functional as F
+        g = F.pad(make_gop(1234, 2, 1080, 1920), (0, 0, 4, 4))
+    else:
+        g = make_gop(1234, 2, h, w)
     refs = ref_list([g[0:1]])
     with torch.no_grad():
         t0 = time.time()
         ref(g[1:2], refs, False)
         dt = time.time() - t0
     frac = (h * w) / float(HP * WP)
-    return {"value": round(frac / dt, 5), "unit": "1080p P-frames/s (area-scaled)", "cores": torch.get_num_threads(),
+    return {"value": round(frac / dt, 5), "unit": "1080p P-frames/s" + ("" if full else " (area-scaled)"), "cores": torch.get_num_threads(),
             "kind": "port", "seconds": round(dt, 2),
-            "sample": f"1 P-frame forward of the fp32 PyTorch oracle at {h}x{w} ({frac:.3f} of the 1088x1920 pixels), fps scaled by area"}
+            "sample": ("1 P-frame forward (cfg-2 frame 1, seed 1234) of the fp32 PyTorch oracle at the full 1088x1920" if full else
+                       f"1 P-frame forward of the fp32 PyTorch oracle at {h}x{w} ({frac:.3f} of the 1088x1920 pixels), fps scaled by area")}
 
 
 REP_LAUNCH = dict(cin=64, cout=64, k=3, H=HP, W=WP)      # the layer shape behind most launches of the dominant kernel
 
 
 def pmc_traffic_bytes():
-    """HBM bytes per representative launch from the committed rocprofv3 --pmc summary (separate FETCH_SIZE /
-    WRITE_SIZE passes; gfx950 correction: wide coalesced reads report half -> 2 x FETCH_SIZE)."""
-    f = os.path.join(ROOT, "profiles", "r01_v7_conv3x3_64_64_1080p_pmc.txt")
+    """HBM bytes per representative launch from the committed rocprofv3 --pmc summary of THIS round's kernel (separate
+    FETCH_SIZE / WRITE_SIZE passes; gfx950 correction: wide coalesced reads report half -> 2 x FETCH_SIZE).  Not measured
+    in the bench run itself (PMC needs the profiler): `traffic_source` names the file; null when it is absent."""
+    f = os.path.join(ROOT, PMC_FILE)
     if not os.path.exists(f):
         return None
     vals = {}
@@ -106,6 +134,55 @@ def pmc_traffic_bytes():
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
+def _time_launches(fn, reps=20):
+    """average duration of `reps` back-to-back launches of fn() on torch's current stream (= the launch stream)"""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def hbm_rooflines(model):
+    """The HBM-bound operators north_star names, each timed live at 1088x1920 on random operands: algorithmic bytes
+    (SURVEY 8d's per-pixel figures) / average launch time / 8 TB/s."""
+    from tdvc_amd import ops
+    dev = "cuda"
+    out = {}
+    P = HP * WP
+
+    def entry(ms, nbytes, what):
+        return {"what": what, "avg_launch_ms": round(ms, 4), "algorithmic_MB": round(nbytes / 1e6, 1),
+                "achieved_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak_GBps": HBM_PEAK / 1e9, "frac": round(nbytes / (ms * 1e-3) / HBM_PEAK, 4)}
+
+    # (1) SPyNet warp at the finest pyramid level: x2 flow upsample + border-mode bilinear warp + 8-channel concat, one kernel
+    r = ops.FM(torch.rand(1, HP, WP, 4, device=dev))
+    s_ = ops.FM(torch.rand(1, HP, WP, 4, device=dev))
+    flo = ops.FM(torch.randn(1, HP // 2, WP // 2, 2, device=dev))
+    up = ops.FM.empty(1, HP, WP, 2, dtype=torch.float32, device=dev)
+    cat8 = ops.FM.empty(1, HP, WP, 8, device=dev)
+    ms = _time_launches(lambda: ops.spynet_level_input(r, s_, flo, up, cat8))
+    out["warp"] = entry(ms, 32.0 * P, "spynet_level_input @1088x1920 (flow_warp + x2 flow upsample + concat; 32 B/px: SURVEY 8d)")
+    # (2) fused DCN (motion compensation): 64 in + 216 offset/mask + 64 out fp16 values per pixel = 688 B/px
+    x = ops.FM(torch.randn(1, HP, WP, 64, device=dev).half())
+    om = ops.FM((torch.randn(1, HP, WP, 216, device=dev) * 1.5).half())
+    y = ops.FM.empty(1, HP, WP, 64, device=dev)
+    dcn = model.mcnet.dconv
+    pc = dcn._pk("w", lambda: ops.pack_conv(dcn.weight, dcn.bias, stride=1, pad=1, ck=8 * dcn.deformable_groups, device=dcn.weight.device))
+    ms = _time_launches(lambda: ops.dcn_fused(x, om, pc, y, groups=8, act=ops.ACT_LRELU, slope=0.1, round16=True))
+    out["dcn_fused"] = entry(ms, 688.0 * P, "dcn_fused @1088x1920, 8 groups, offsets ~N(0, 1.5 px) (688 B/px fp16: SURVEY 8d)")
+    # (3) SELayer on a 64-channel full-resolution map: read for the pool, read for the scale, write = 3 x 64 fp16 values per pixel
+    se = model.motion_est.attn
+    o = ops.FM.empty(1, HP, WP, 64, device=dev)
+    ms = _time_launches(lambda: se.run(x, out=o))
+    out["se"] = entry(ms, 3.0 * 64 * 2 * P, "SELayer(64) @1088x1920: channel_sum + se_gate + scale_act_res (3 x C values/px: SURVEY 8d)")
+    return out
 
 
 def roofline_leg(runner):
@@ -131,21 +208,16 @@ def roofline_leg(runner):
     x = ops.FM(torch.randn(1, L["H"], L["W"], L["cin"], device="cuda").half())
     pc = ops.pack_conv(torch.randn(L["cout"], L["cin"], L["k"], L["k"]) * 0.04, torch.zeros(L["cout"]), stride=1, pad=1)
     y = ops.conv(x, pc, act=ops.ACT_RELU)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20):
-        ops.conv(x, pc, out=y, act=ops.ACT_RELU)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 20
+    rep_kernel = ops.L.lib().tdvc_last_conv_kernel().decode()
+    ms = _time_launches(lambda: ops.conv(x, pc, out=y, act=ops.ACT_RELU))
     flop = 2.0 * L["H"] * L["W"] * L["cout"] * L["cin"] * L["k"] ** 2
     alg_bytes = 2.0 * L["H"] * L["W"] * (L["cin"] + L["cout"])
     ach = flop / (ms * 1e-3) / 1e12
     traffic = pmc_traffic_bytes()
-    return {"bound": "mfma", "kernel": name, "launch": "3x3 64->64 stride 1 @1088x1920 (154.0 GFLOP, 534.8 MB algorithmic)",
+    return {"bound": "mfma", "kernel": name, "launch": f"3x3 64->64 stride 1 @1088x1920 on {rep_kernel} (154.0 GFLOP, 534.8 MB algorithmic)",
             "achieved": round(ach, 2), "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / MFMA_F16_PEAK, 4),
             "avg_launch_ms": round(ms, 4), "traffic": traffic,
+            "traffic_source": (PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; not measured in this run)") if traffic else None,
             "hbm_side": {"algorithmic_GBps": round(alg_bytes / (ms * 1e-3) / 1e9, 1), "peak_GBps": 8000.0,
                          "frac": round(alg_bytes / (ms * 1e-3) / 8e12, 4)},
             "frame_kernel": {"launches_per_frame": a["n"], "ms_per_frame": round(a["ms"], 3),
@@ -155,10 +227,10 @@ def roofline_leg(runner):
                           for k, v in sorted(agg.items())}}
 
 
-def train_leg(a, rank, world, dev, dist):
+def train_measure(B, steps, warmup, rank, gpus, dev, dist, graph=False):
     """BASELINE.json configs[2] (1 GPU) / [3] (N GPUs): one optimisation step (forward, backward incl. both entropy
-    models, RCCL gradient mean over ranks, clipping, Adam, aux step, re-packing) on `--train-batch` 256x256 P-frame
-    samples per rank (weak scaling: the reference's batch 32 over 8 GPUs)."""
+    models, RCCL gradient mean over ranks, clipping, Adam, aux step, re-packing) on B 256x256 P-frame samples per rank
+    (weak scaling: the reference's batch 32 over 8 GPUs).  -> (seconds for `steps` steps, max over ranks; last log)"""
     from tdvc_amd.model import VideoCompressor
     from tdvc_amd.synth import fill_parameters, make_gop, ref_list
     from tdvc_amd.train import TrainStep
@@ -166,24 +238,23 @@ def train_leg(a, rank, world, dev, dist):
     m = VideoCompressor()
     fill_parameters(m)
     m = m.to(dev).train()
-    B = a.train_batch
     xs, rs = [], []
     for i in range(B):                                   # seeds 1000 + sample index
         g = make_gop(1000 + rank * B + i, 7, 256, 256).to(dev)
         xs.append(g[3:4])
         rs.append(ref_list([g[0:1], g[1:2], g[2:3]]))
     x, refs = torch.cat(xs), torch.cat(rs)
-    step = TrainStep(m, train_lambda=2048.0, lr=1e-4, loss_scale=128.0, graph=a.graph)
-    for _ in range(2 if a.graph else 0):                 # eager steps that precede the capture (not part of --warmup)
+    step = TrainStep(m, train_lambda=2048.0, lr=1e-4, loss_scale=128.0, graph=graph)
+    for _ in range(2 if graph else 0):                   # eager steps that precede the capture (not part of --warmup)
         step(x, refs)
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         log = step(x, refs)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         log = step(x, refs)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -192,21 +263,21 @@ def train_leg(a, rank, world, dev, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.barrier()
         dt = float(t)
-    if rank == 0:
-        sps = a.gpus * B * a.steps / dt
-        flop_step = 3.0 * FLOP_PER_PX * 256 * 256 * B          # training ~ 3x the forward
-        print(json.dumps({
-            "metric": "256x256 P-frame training samples/sec (forward + backward + optimizer step, lambda=2048)", "value": round(sps, 3),
-            "unit": "samples/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+    return dt, log
+
+
+def train_record(B, steps, warmup, gpus, dt, log):
+    flop_step = 3.0 * FLOP_PER_PX * 256 * 256 * B          # training ~ 3x the forward
+    return {"metric": "256x256 P-frame training samples/sec (forward + backward + optimizer step, lambda=2048)",
+            "value": round(gpus * B * steps / dt, 3), "unit": "samples/s", "n_gpus": gpus, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(1e3 * dt / steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "data": "synthetic",
             "config": {"workload": f"{B} x 256x256 P-frame samples per rank (septuplet frame 3, refs [I,I,x1,x2]), full fwd/bwd incl. entropy models",
-                       "global_batch": B * a.gpus, "parallelism": f"data-parallel x{a.gpus} (RCCL gradient mean, 16 MB buckets in gradient-completion order, all-reduced under the backward sweep)",
+                       "global_batch": B * gpus,
+                       "parallelism": f"data-parallel x{gpus} (RCCL gradient mean, 16 MB buckets in gradient-completion order, all-reduced under the backward sweep)",
                        "weights": "closed-form filler (no checkpoint ships)"},
-            "whole_step_tflops": round(flop_step * a.steps / dt / 1e12, 2),
-            "rd_loss_last": round(log["rd_loss"], 4), "grad_norm_last": round(log["grad_norm"], 3)}))
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+            "whole_step_tflops": round(flop_step * steps / dt / 1e12, 2),
+            "rd_loss_last": round(log["rd_loss"], 4), "grad_norm_last": round(log["grad_norm"], 3)}
 
 
 def main():
@@ -215,29 +286,45 @@ def main():
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="1088x1920", help="HxW of the CPU-oracle frame (default: the real 1088x1920 frame, about a minute)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32-island, HBM-roofline and training legs of the N=1 line")
     ap.add_argument("--mode", choices=("infer", "train"), default="infer",
                     help="infer (default, the headline metric) | train: BASELINE.json configs[2]/[3], one optimisation step per step")
     ap.add_argument("--graph", action="store_true", help="--mode train: replay the forward + backward as one captured HIP graph")
     ap.add_argument("--train-batch", type=int, default=4, help="samples per rank in --mode train (256x256 P-frames)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:       # no launcher: start the ranks ourselves, before any GPU call
+        sys.exit(self_launch(sys.argv[1:], a.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
+    def finish_dist():
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+
     if a.mode == "train":
-        train_leg(a, rank, world, dev, dist)
+        dt, log = train_measure(a.train_batch, a.steps, a.warmup, rank, a.gpus, dev, dist, a.graph)
+        finish_dist()
+        if rank == 0:
+            print(json.dumps(train_record(a.train_batch, a.steps, a.warmup, a.gpus, dt, log)))
         return
+
     model = build_model(dev)
-    gop = make_inputs(2000 + 100 * rank, dev)           # independent GOP per rank (SURVEY §8d seeds)
+    # SURVEY §8d seeds: cfg-2 (one GPU) codes the GOP of seed 1234; the GOP-sharded runs give every rank its own GOP
+    gop = make_inputs(1234 if world == 1 else 2000 + 100 * rank, dev)
     runner = GopRunner(model, gop)
     for _ in range(a.warmup):
         runner.step()
@@ -256,29 +343,55 @@ def main():
         dist.barrier()
         dt = float(t)
     torch.cuda.synchronize()
+    finish_dist()                      # the other ranks are done: the legs below are rank 0's alone (no rank waits in a barrier)
+    if rank != 0:
+        return
 
-    if rank == 0:
-        fps = a.gpus * a.steps / dt
-        roof = roofline_leg(runner)
-        line = {
-            "metric": "1080p P-frames/sec (encode + reconstruct, lambda=2048 config)", "value": round(fps, 3),
-            "unit": "frames/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "1x 1920x1080 (padded 1088x1920) 7-frame synthetic GOP, batch 1, P-frames coded in GOP order",
-                       "gop": 7, "batch": 1, "parallelism": f"gop-sharded x{a.gpus}", "weights": "closed-form filler (no checkpoint ships)"},
-            "whole_path_tflops": round(FLOP_PER_PX * HP * WP * fps / a.gpus / 1e12, 2),
-            "whole_path_frac_of_mfma_peak": round(FLOP_PER_PX * HP * WP * fps / a.gpus / MFMA_F16_PEAK, 4),
-            "bpp_last": round(float(bpp_res + bpp_mv), 5),
-            "roofline": roof,
-        }
-        print("[bench] gpu leg: " + json.dumps(line), file=sys.stderr, flush=True)
-        if a.gpus == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line))
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    fps = a.gpus * a.steps / dt
+    roof = roofline_leg(runner)
+    line = {
+        "metric": "1080p P-frames/sec (encode + reconstruct, lambda=2048 config)", "value": round(fps, 3),
+        "unit": "frames/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": "1x 1920x1080 (padded 1088x1920) 7-frame synthetic GOP (seed 1234), batch 1, P-frames coded in GOP order",
+                   "gop": 7, "batch": 1, "parallelism": f"gop-sharded x{a.gpus}", "weights": "closed-form filler (no checkpoint ships)",
+                   "coders": "fp16-in / fp32-accumulate (default, enabled_amp=True); the fp32-island mode (enabled_amp=False) is `fp32_islands` below",
+                   "encode": "VideoCompressor.forward with estimated bits, as tools/predict.py (is_compress never set); real range-coded encode/decode: DESIGN.md §1"},
+        "whole_path_tflops": round(FLOP_PER_PX * HP * WP * fps / a.gpus / 1e12, 2),
+        "whole_path_frac_of_mfma_peak": round(FLOP_PER_PX * HP * WP * fps / a.gpus / MFMA_F16_PEAK, 4),
+        "bpp_last": round(float(bpp_res + bpp_mv), 5),
+        "roofline": roof,
+    }
+    if a.gpus == 1 and not a.no_extras:
+        line["roofline_hbm"] = hbm_rooflines(model)
+        try:                                           # the same frames with both coders as fp32 islands (pnet.py:33,57)
+            if not getattr(model, "fp32_islands_supported", False):
+                raise RuntimeError("this build has no fp32-island mode")
+            r32 = GopRunner(model, gop, enabled_amp=False)
+            for _ in range(2):
+                r32.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n32 = max(3, a.steps // 3)
+            for _ in range(n32):
+                r32.step()
+            torch.cuda.synchronize()
+            d32 = time.perf_counter() - t1
+            line["fp32_islands"] = {"value": round(n32 / d32, 3), "unit": "frames/s", "steps": n32, "ms_per_step": round(1e3 * d32 / n32, 3),
+                                    "what": "enabled_amp=False: g_a / h_a / h_s / context / entropy_parameters / g_s of both coders in fp32 (v_mfma_f32_32x32x2_f32)"}
+        except Exception as ex:                        # never lose the headline line to an optional leg
+            line["fp32_islands"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+        del model, runner
+        torch.cuda.empty_cache()
+        tsteps = 15
+        tdt, tlog = train_measure(4, tsteps, 3, 0, 1, dev, None)
+        line["train_step"] = train_record(4, tsteps, 3, 1, tdt, tlog)
+    print("[bench] gpu leg: " + json.dumps(line), file=sys.stderr, flush=True)
+    if a.gpus == 1 and not a.no_cpu_baseline:
+        h, w = (int(v) for v in a.cpu_sample.lower().split("x"))
+        line["cpu_baseline"] = cpu_baseline((h, w))
+    print(json.dumps(line))
 
 
 if __name__ == "__main__":

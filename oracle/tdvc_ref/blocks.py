@@ -422,7 +422,8 @@ class FeatureFix(nn.Module):
         fin = self.FeatureExtract_input(x)
         fref = self.FeatureExtract_ref(iframe)
         scale = 8 if self.training else int(fin.shape[2] / 8)
-        _, out = self.match(fin, fref, scale)
+        ind, out = self.match(fin, fref, scale)
+        self.last_match_index = ind          # (N, L) argmax per input patch: what the parity tests compare bit for bit
         cor = F.cosine_similarity(fin, out).unsqueeze(1)
         o = F.leaky_relu(self.featfusion(torch.cat([fin, out], 1) * cor), 0.1)
         o = F.leaky_relu(self.attn(self.featfusion2(torch.cat([o, fref], 1))), 0.1)

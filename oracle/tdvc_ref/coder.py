@@ -26,15 +26,31 @@ from .blocks import SELayer
 
 
 # ------------------------------------------------------------------ parametrizers / GDN
+class _LowerBoundFn(torch.autograd.Function):
+    """compressai ops/bound_ops.py (`LowerBoundFunction`): forward max(x, bound); the backward passes the gradient
+    where `x >= bound` OR `grad_output < 0` (a value pinned at the bound can still be pushed up, away from it), and
+    gives the bound no gradient.  The reference trains through this rule (compressai's entropy models and GDN)."""
+
+    @staticmethod
+    def forward(ctx, x, bound):
+        ctx.save_for_backward(x, bound)
+        return torch.max(x, bound)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, bound = ctx.saved_tensors
+        return ((x >= bound) | (g < 0)).to(g.dtype) * g, None
+
+
 class LowerBound(nn.Module):
-    """max(x, bound) with buffer `bound` (compressai ops/bound_ops.py)."""
+    """max(x, bound) with buffer `bound` and compressai's pass-through gradient rule (ops/bound_ops.py)."""
 
     def __init__(self, bound):
         super().__init__()
         self.register_buffer("bound", torch.Tensor([float(bound)]))
 
     def forward(self, x):
-        return torch.max(x, self.bound)
+        return _LowerBoundFn.apply(x, self.bound)
 
 
 class NonNegativeParametrizer(nn.Module):
@@ -188,7 +204,19 @@ def _pmf_table_to_cdf(pmf, tail_mass, pmf_length, max_length, precision=16):
 
 
 # ------------------------------------------------------------------ entropy models
-class EntropyBottleneck(nn.Module):
+class _CdfBuffers:
+    """compressai `update_registered_buffers`: the table buffers are empty until update(); loading a checkpoint that
+    carries them filled resizes them first"""
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        for n in ("_quantized_cdf", "_offset", "_cdf_length", "scale_table"):
+            src, buf = state_dict.get(prefix + n), self._buffers.get(n)
+            if src is not None and buf is not None and buf.shape != src.shape:
+                self._buffers[n] = torch.empty(src.shape, dtype=buf.dtype, device=buf.device)
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
+class EntropyBottleneck(_CdfBuffers, nn.Module):
     """Factorised prior (compressai entropy_models.py, 1.1.x parameter names
     `_matrix{i}`, `_bias{i}`, `_factor{i}`, `quantiles`)."""
 
@@ -296,7 +324,7 @@ def get_scale_table():
     return torch.exp(torch.linspace(math.log(SCALES_MIN), math.log(SCALES_MAX), SCALES_LEVELS))
 
 
-class GaussianConditional(nn.Module):
+class GaussianConditional(_CdfBuffers, nn.Module):
     """compressai entropy_models.py GaussianConditional(scale_table=None)."""
 
     def __init__(self, scale_bound=0.11, tail_mass=1e-9, likelihood_bound=1e-9):

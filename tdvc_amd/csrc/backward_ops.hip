@@ -689,8 +689,11 @@ __global__ __launch_bounds__(256) void eb_backward_kernel(FMap z, const float* p
     const float diff = su - sl;
     const float lik = fabsf(diff);
     float dv = 0.f;
-    if (lik > 1e-9f) {
-      const float dlik = -gscale / (lik * 0.69314718055994531f);           // d(-log2 lik)
+    // likelihood floor = compressai's LowerBound (ops/bound_ops.py): the gradient passes where lik >= bound OR it is
+    // negative; d(-log2 max(lik, 1e-9)) / d lik is negative whenever gscale > 0, so a latent on the floor keeps a gradient
+    const float likb = fmaxf(lik, 1e-9f);
+    const float dlik = -gscale / (likb * 0.69314718055994531f);            // d(-log2 max(lik, 1e-9)) w.r.t. the bounded value
+    if (lik >= 1e-9f || dlik < 0.f) {
       const float sd = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
       const float gup = dlik * sd * su * (1.f - su) * sign;
       const float glo = -dlik * sd * sl * (1.f - sl) * sign;
@@ -711,7 +714,7 @@ __global__ __launch_bounds__(256) void eb_backward_kernel(FMap z, const float* p
 }
 
 // Gaussian conditional with additive noise: bits = -log2 max(Phi((.5 - v)/s) - Phi((-.5 - v)/s), 1e-9), v = |y + noise - mean|,
-// s = max(scale, 0.11): dy, dmean (= -dy), dscale (zero below the bound, as the oracle's plain max)
+// s = max(scale, 0.11): dy, dmean (= -dy), dscale (below the bound only a NEGATIVE gradient passes: compressai LowerBound)
 __global__ void gc_backward_kernel(FMap y, FMap gp, FMap noise, float gscale, FMap dy, FMap dgp) {
   const long npix = (long)y.H * y.W;
   const long total = npix * y.C * y.N;
@@ -730,16 +733,18 @@ __global__ void gc_backward_kernel(FMap y, FMap gp, FMap noise, float gscale, FM
   const float k = 0.70710678118654752440f;
   const float a = (0.5f - v) / s, b = (-0.5f - v) / s;
   const float lik = 0.5f * erfcf(-k * a) - 0.5f * erfcf(-k * b);
-  if (!(lik > 1e-9f)) return;
+  // both bounds follow compressai's LowerBound backward (ops/bound_ops.py): pass where x >= bound OR the gradient is negative
+  const float dlik = -gscale / (fmaxf(lik, 1e-9f) * 0.69314718055994531f);
+  if (!(lik >= 1e-9f || dlik < 0.f)) return;
   const float inv_sqrt_2pi = 0.39894228040143267794f;
   const float pa = inv_sqrt_2pi * expf(-0.5f * a * a), pb = inv_sqrt_2pi * expf(-0.5f * b * b);
-  const float dlik = -gscale / (lik * 0.69314718055994531f);
   const float dv = dlik * (pb - pa) / s;
   const float du = dv * (u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f));
   reinterpret_cast<float*>(dy.p)[(long)n * dy.sn + pix * dy.sp + c] += du;
   float* dg = reinterpret_cast<float*>(dgp.p) + (long)n * dgp.sn + pix * dgp.sp;
   dg[y.C + c] -= du;
-  if (sc > 0.11f) dg[c] += dlik * (b * pb - a * pa) / s;
+  const float ds = dlik * (b * pb - a * pa) / s;          // gradient w.r.t. the bounded scale
+  if (sc >= 0.11f || ds < 0.f) dg[c] += ds;
 }
 
 }  // namespace

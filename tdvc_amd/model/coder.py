@@ -21,10 +21,29 @@ from .modules import PackCache, SELayer, pk_conv
 
 
 # ------------------------------------------------------------------ parameter holders
+class _LowerBoundGrad(torch.autograd.Function):
+    """max(x, bound) whose backward follows compressai's `LowerBoundFunction` (ops/bound_ops.py): the gradient passes
+    where `x >= bound` or `grad < 0`.  Parameter-space use only (GDN beta / gamma chain rule); the activation-space
+    bounds (likelihood floor, scale bound) apply the same rule inside `tdvc_eb_backward` / `tdvc_gc_backward`."""
+
+    @staticmethod
+    def forward(ctx, x, bound):
+        ctx.save_for_backward(x, bound)
+        return torch.max(x, bound)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, bound = ctx.saved_tensors
+        return ((x >= bound) | (g < 0)).to(g.dtype) * g, None
+
+
 class LowerBound(nn.Module):
     def __init__(self, bound):
         super().__init__()
         self.register_buffer("bound", torch.Tensor([float(bound)]))
+
+    def forward(self, x):
+        return _LowerBoundGrad.apply(x, self.bound)
 
 
 class NonNegativeParametrizer(nn.Module):
@@ -38,7 +57,7 @@ class NonNegativeParametrizer(nn.Module):
         return torch.sqrt(torch.max(x + self.pedestal, self.pedestal))
 
     def effective(self, x):
-        return torch.max(x, self.lower_bound.bound) ** 2 - self.pedestal
+        return self.lower_bound(x) ** 2 - self.pedestal
 
 
 class GDN(nn.Module, PackCache):
@@ -153,7 +172,24 @@ class MaskedConv2d(nn.Conv2d):
         return [(dy, dx) for dy in range(h) for dx in range(w) if dy < h // 2 or (dy == h // 2 and dx < w // 2)]
 
 
-class EntropyBottleneck(nn.Module, PackCache):
+class _CdfBuffers:
+    """mixin: the coder tables (`_quantized_cdf`, `_offset`, `_cdf_length`, `scale_table`) are buffers that are EMPTY
+    until `update()` runs; a checkpoint saved after an update carries them filled.  Like compressai's
+    `update_registered_buffers`, loading resizes the module's buffers to whatever the checkpoint holds, so
+    `load_state_dict(strict=True)` works in both directions (tools/predict.py:150)."""
+
+    _cdf_buffer_names = ("_quantized_cdf", "_offset", "_cdf_length", "scale_table")
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        for n in self._cdf_buffer_names:
+            src = state_dict.get(prefix + n)
+            buf = self._buffers.get(n)
+            if src is not None and buf is not None and buf.shape != src.shape:
+                self._buffers[n] = torch.empty(src.shape, dtype=buf.dtype, device=buf.device)
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
+class EntropyBottleneck(_CdfBuffers, nn.Module, PackCache):
     """factorised prior parameters (CompressAI 1.1.x names)"""
 
     def __init__(self, channels, tail_mass=1e-9, init_scale=10, filters=(3, 3, 3, 3), likelihood_bound=1e-9):
@@ -228,7 +264,7 @@ class EntropyBottleneck(nn.Module, PackCache):
         return torch.abs(logits - self.target).sum()
 
 
-class GaussianConditional(nn.Module):
+class GaussianConditional(_CdfBuffers, nn.Module):
     def __init__(self, scale_bound=0.11, tail_mass=1e-9, likelihood_bound=1e-9):
         super().__init__()
         self.tail_mass = float(tail_mass)
@@ -423,11 +459,14 @@ class Cheng2020Anchor(nn.Module, PackCache):
     def _ctx_1x1(self) -> ops.PackedConv:
         """the masked 5x5 context conv as a 1x1 conv over gathered 12-tap neighbourhoods"""
         cp = self.context_prediction
+
         def build():
-            w = cp.weight.detach().float().cpu()
-            cols = [w[:, :, dy, dx] for dy, dx in cp.live_taps()]
-            w1 = torch.cat(cols, 1).reshape(w.shape[0], -1, 1, 1)          # (2M, 12*M, 1, 1), tap-major
-            return ops.pack_conv(w1, cp.bias, stride=1, pad=0, device=cp.weight.device)
+            # (2M, 12*M, 1, 1), tap-major, gathered straight from the parameter (a view, not a snapshot: PackBatch /
+            # refresh_packed re-pack it from the live weights after every optimizer step, like every other layer form)
+            co, ci, kh, kw = cp.weight.shape
+            chan = np.array([c * kh * kw + dy * kw + dx for dy, dx in cp.live_taps() for c in range(ci)], dtype=np.int64)
+            lay = ops.convpack.WeightLayout(co, len(chan), 1, 1, np.arange(co, dtype=np.int64) * ci * kh * kw, chan, np.zeros(1, dtype=np.int64))
+            return ops.pack_conv(cp.weight, cp.bias, stride=1, pad=0, device=cp.weight.device, layout=lay, param_w=cp.weight, param_b=cp.bias)
         return self._pk("ctx1x1", build)
 
     @staticmethod

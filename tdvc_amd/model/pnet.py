@@ -34,6 +34,7 @@ class VideoCompressor(nn.Module):
     def clear_packed(self):
         for m in self.modules():
             m.__dict__.pop("_packed", None)
+            m.__dict__.pop("_tables", None)         # host copies of the coder CDF tables (Cheng2020Anchor._coder_tables)
 
     def load_state_dict(self, *a, **kw):
         r = super().load_state_dict(*a, **kw)

@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--pretrain", default="")
     ap.add_argument("--save-dir", default="")
     ap.add_argument("--save-every", type=int, default=10000)
+    ap.add_argument("--latest-every", type=int, default=2000, help="iterations between latest.pth saves (tools/train.py:168,196: every 2000)")
     ap.add_argument("--seed", type=int, default=1000)
     ap.add_argument("--vimeo", default="", help="Vimeo-septuplet root (<dir>/<clip>/im1..7.png): tdvc_amd.data.DataSet with the "
                                                 "reference's sample rule and augmentation (train.py:78-80); default: synthetic septuplets")
@@ -115,7 +116,7 @@ def main():
             print(json.dumps({"iter": it + 1, "rd_loss": round(log["rd_loss"], 4), "psnr": round(psnr, 3),
                               "bpp": round(log["bpp_res"] + log["bpp_mv"], 4), "aux": round(log["aux_loss"], 2),
                               "grad_norm": round(log["grad_norm"], 3), "s_per_iter": round((time.time() - t0) / (it + 1), 3)}), flush=True)
-            if a.save_dir:
+            if a.save_dir and ((it + 1) % a.latest_every == 0 or (it + 1) % a.save_every == 0 or it + 1 == a.iters):
                 os.makedirs(a.save_dir, exist_ok=True)
                 torch.save(net.state_dict(), os.path.join(a.save_dir, "latest.pth"))
                 if (it + 1) % a.save_every == 0:

@@ -496,3 +496,120 @@ def test_train_step_overflow_policy(report):
     assert not logs[-1]["skipped"] and logs[-1]["grad_norm"] == logs[-1]["grad_norm"]
     assert not torch.equal(before, torch.cat([p.detach().reshape(-1) for p in step.main_params]))
     report(f"overflow policy: {sum(l['skipped'] for l in logs)} skipped steps, loss scale 2^30 -> {logs[-1]['loss_scale']:.0f}, then rd_loss {logs[-1]['rd_loss']:.3f}")
+
+
+def test_rate_bounds_backward(report):
+    """`tdvc_gc_backward` / `tdvc_eb_backward` at, below and above the LowerBounds (scale bound 0.11, likelihood floor
+    1e-9) against the oracle's autograd, whose LowerBound carries compressai's published rule (pass where x >= bound OR
+    grad < 0; pinned by hand-computed vectors in tests/test_oracle_coder.py): a scale under the bound keeps its (negative)
+    gradient, a latent on the likelihood floor keeps a gradient."""
+    from oracle.tdvc_ref import coder as oc
+    from tdvc_amd import ops
+    from tdvc_amd.model.coder import EntropyBottleneck
+    from tdvc_amd.synth import fill_parameters
+    C, H, W = 8, 4, 8
+    g = torch.Generator().manual_seed(91)
+    means = torch.randn(1, C, H, W, generator=g)
+    y = means + torch.randn(1, C, H, W, generator=g) * 0.8
+    scales = torch.rand(1, C, H, W, generator=g) * 1.2 - 0.1            # about a sixth below 0.11, some negative
+    y[0, 0, 0, :4] = torch.tensor([25.0, -30.0, 40.0, 18.0])            # on the likelihood floor
+    scales[0, 0, 0, :4] = torch.tensor([0.05, 0.2, 0.5, 0.11])
+    noise = torch.rand(1, C, H, W, generator=g) - 0.5
+    sc_r, mu_r, y_r = scales.clone().requires_grad_(), means.clone().requires_grad_(), y.clone().requires_grad_()
+    gc = oc.GaussianConditional()
+    _, lik = gc(y_r, sc_r, mu_r, True, noise)
+    assert int((lik <= 1e-9).sum()) >= 3 and int((scales < 0.11).sum()) >= 20 and int((lik > 1e-9).sum()) >= 200
+    (-torch.log2(lik)).sum().backward()
+    yf, nf = to_fm(y, ops, C, torch.float32), to_fm(noise, ops, C, torch.float32)
+    gp = to_fm(torch.cat([scales, means], 1), ops, 2 * C, torch.float32)
+    dy = ops.FM.zeros(1, H, W, C, dtype=torch.float32)
+    dgp = ops.FM.zeros(1, H, W, 2 * C, dtype=torch.float32)
+    ops.gc_backward(yf, gp, nf, 1.0, dy, dgp)
+    got_dy, got_dgp = fm_to_cpu(dy), fm_to_cpu(dgp)
+    below = scales < 0.11
+    report(f"gc bounds: {int(below.sum())} scales under the bound, {int((sc_r.grad[below] != 0).sum())} of them with a (negative) gradient; "
+           f"{int((lik <= 1e-9).sum())} latents on the likelihood floor")
+    assert float(sc_r.grad[below].max()) <= 0.0 and int((sc_r.grad[below] < 0).sum()) > 0
+    gb, rb = got_dgp[:, :C][below], sc_r.grad[below]
+    assert bool((gb[rb.abs() > 1e-5] < 0).all()) and float(gb[rb == 0].abs().max()) < 1e-5, "which under-bound scales receive a gradient"
+    for name, got, want in (("dy", got_dy, y_r.grad), ("dscale", got_dgp[:, :C], sc_r.grad), ("dmean", got_dgp[:, C:], mu_r.grad)):
+        e = _rel(got, want)
+        report(f"gc bounds {name}: rel L2 err {e:.3e}")
+        assert e < 2e-3, name
+    # factorised prior: latents far in the tail sit on the 1e-9 floor and must keep a gradient
+    ref = oc.EntropyBottleneck(C)
+    h = torch.nn.Module(); h.add_module("entropy_bottleneck", ref); fill_parameters(h)
+    ref.train()
+    eb = EntropyBottleneck(C)
+    eb.load_state_dict(ref.state_dict())
+    eb.cuda()
+    z = torch.randn(1, C, 2, 4, generator=g) * 4.0
+    z[0, :, 0, 0] = 400.0
+    z[0, :, 1, 3] = -350.0
+    nz = torch.rand(1, C, 2, 4, generator=g) - 0.5
+    z_r = z.clone().requires_grad_()
+    _, zl = ref(z_r, nz)
+    assert int((zl <= 1e-9).sum()) >= 2 * C
+    (-torch.log2(zl)).sum().backward()
+    dz = ops.FM.zeros(1, 2, 4, C, dtype=torch.float32)
+    dpar = torch.zeros(C, 59, device="cuda")
+    ops.eb_backward(to_fm(z, ops, C, torch.float32), eb.packed_params(), to_fm(nz, ops, C, torch.float32), 1.0, dz, dpar)
+    e = _rel(fm_to_cpu(dz), z_r.grad)
+    report(f"eb bounds dz: rel L2 err {e:.3e}; floor latents with gradient: oracle {int((z_r.grad[zl <= 1e-9] != 0).sum())}")
+    assert e < 5e-3
+
+
+def test_full_model_backward_cfg3_shape(report):
+    """BASELINE.json configs[2] geometry (batch >= 2 of 256x256 samples): the dispatches TrainStep / bench actually take
+    (v3 / v7 dgrad instead of the small-map kernel, multi-worker weight-gradient partials, batch in grid.z, the per-batch
+    `as_slices` loop of the fusion block) against the oracle's autograd, every parameter gradient."""
+    from oracle.tdvc_ref.codec import VideoCompressor as RefVC
+    from tdvc_amd import autograd, ops, synth
+    from tdvc_amd.model.pnet import VideoCompressor
+    ref = RefVC()
+    synth.fill_parameters(ref)
+    dev = VideoCompressor()
+    dev.load_state_dict(ref.state_dict())
+    dev = dev.cuda()
+    dev.train()
+    ref.train()
+    B, H, W, lam = 2, 256, 256, 2048.0
+    xs, rs = [], []
+    for i in range(B):                                        # SURVEY 8d: cfg-3 seeds 1000 + sample index
+        gop = synth.make_gop(1000 + i, 7, H, W)
+        xs.append(gop[3:4])
+        rs.append(synth.ref_list([gop[0:1], gop[1:2], gop[2:3]]))
+    x, refs = torch.cat(xs), torch.cat(rs)
+    g = torch.Generator().manual_seed(72)
+    u = lambda *s: torch.rand(*s, generator=g) - 0.5
+    mk = lambda: {"z": u(B, 128, H // 64, W // 64), "y": u(B, 128, H // 16, W // 16), "y_lik": u(B, 128, H // 16, W // 16)}
+    noise = {"mv": mk(), "res": mk()}
+    recon, bpp_res, bpp_mv, _, _ = ref(x, refs, noise=noise)
+    loss = lam * torch.nn.functional.mse_loss(recon, x) + bpp_res.mean() + bpp_mv.mean()
+    loss.backward()
+    with autograd.record() as tape:
+        nf = {k: {kk: to_fm(v, ops, Cpad=128, dtype=torch.float32) for kk, v in d.items()} for k, d in noise.items()}
+        r, br, bm, _, _ = dev(x.cuda(), refs.cuda(), True, noise=nf)
+        diff = r - x.cuda()
+        tape.grad_tensor(r).copy_(diff * (2.0 * lam / diff.numel()))
+        tape.rate_grad = 1.0 / float(B * H * W)
+        tape.backward()
+    dl = float(lam * (diff * diff).mean() + br.mean() + bm.mean())
+    report(f"cfg-3 shape ({B}x{H}x{W}) rd_loss: device {dl:.5f} oracle {float(loss):.5f}")
+    assert abs(dl - float(loss)) < 1e-2 * abs(float(loss))
+    errs, gd, gr = [], [], []
+    for (k, p), (k2, q) in zip(dev.named_parameters(), ref.named_parameters()):
+        assert k == k2
+        if q.grad is None or float(q.grad.norm()) == 0.0 or k.endswith(".quantiles"):
+            continue
+        assert p.grad is not None, k
+        errs.append((_rel(p.grad.cpu(), q.grad), k))
+        gd.append(p.grad.reshape(-1).cpu())
+        gr.append(q.grad.reshape(-1))
+    errs.sort()
+    tot = _rel(torch.cat(gd), torch.cat(gr))
+    report(f"cfg-3 shape: {len(errs)} parameter gradients, whole-gradient rel L2 err {tot:.3e}, per tensor median {errs[len(errs) // 2][0]:.3e}, "
+           f"90% {errs[int(0.9 * len(errs))][0]:.3e}, worst {[(f'{e:.3e}', k) for e, k in errs[-6:]]}")
+    # whole gradient <= 2e-2; per tensor: 90 % under 6e-2, none above 0.2 (fp16 activations / activation gradients: sign
+    # flips of ReLU / LeakyReLU pre-activations near zero dominate the small tensors)
+    assert tot < 2e-2 and errs[int(0.9 * len(errs))][0] < 6e-2 and errs[-1][0] < 0.2

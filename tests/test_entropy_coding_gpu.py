@@ -69,8 +69,17 @@ def test_compress_roundtrip_and_bitstream(coders, H, W, report):
     report(f"compress {H}x{W}: coded {act:.0f} bits, forward estimate {est:.0f}, oracle coded {act_o:.0f}; symbol mismatch vs fp32 oracle {flips:.4f}")
     assert abs(act - act_o) <= 0.02 * act_o + 64
     assert 0.7 * act < est < 1.3 * act + 512
-    assert flips < 0.02
-    assert zs[0] == enc_o["strings"][1][0] or True      # z symbols may flip under fp16; informational
+    # fp16 coders (the default mode): round() sees fp16 activations upstream, so a stated fraction of the symbols may
+    # land in the neighbouring bin; byte-equal streams on identical inputs are the fp32-island mode's gate
+    # (test_fp32_island_bitstreams_equal_oracle).  Ceilings: 2 % of the y symbols, 2 % of the z symbols.
+    eb = ref.entropy_bottleneck
+    zh, zw = enc["shape"]
+    zi = torch.arange(128, dtype=torch.int32).view(-1, 1, 1).expand(128, zh, zw).reshape(-1).tolist()
+    zdec = lambda s: oc.RansDecoder(s).decode(zi, eb._quantized_cdf.tolist(), eb._cdf_length.tolist(), eb._offset.tolist())
+    zg, zo = zdec(zs[0]), zdec(enc_o["strings"][1][0])
+    zflips = sum(a != b for a, b in zip(zg, zo)) / len(zo)
+    report(f"compress {H}x{W}: z symbol mismatch vs fp32 oracle {zflips:.4f} ({len(zo)} symbols)")
+    assert flips < 0.02 and zflips <= 0.02
 
 
 def test_forward_is_compress_flag(report):
@@ -128,3 +137,39 @@ def test_frame_encode_container_decode_roundtrip(report):
     b2.seek(0)
     s2, sh2 = bitstream.read_records(b2, 1)
     assert s2 == big and tuple(sh2[0]) == (1, 2, 3, 4)
+
+
+def test_encode_after_train_step_decodes_in_fresh_model(report):
+    """encode -> one TrainStep -> encode, then decode in a FRESH model built from the saved state_dict: every packed layer
+    form the entropy coder uses (the context conv's 1x1 form included) must follow the optimizer step, or a decoder in
+    another process desynchronises on the y stream."""
+    from tdvc_amd import synth
+    from tdvc_amd.model import VideoCompressor
+    from tdvc_amd.train import TrainStep
+    net = VideoCompressor()
+    synth.fill_parameters(net)
+    net = net.cuda().eval()
+    H = W = 64
+    gop = synth.make_gop(78, 7, H, W).cuda()
+    refs = synth.ref_list([gop[0:1], gop[1:2], gop[2:3]])
+    x = gop[3:4]
+    enc0 = net.encode(x, refs)                                   # builds every packed form once, before the step
+    net.train()
+    step = TrainStep(net, train_lambda=2048.0, lr=1e-3, loss_scale=128.0)
+    torch.manual_seed(0)
+    log = step(x, refs)
+    assert log["rd_loss"] == log["rd_loss"]
+    net.eval()
+    net.mvCoder.update(force=True)
+    net.resCoder.update(force=True)
+    enc1 = net.encode(x, refs)
+    assert enc1["strings"][0][0] != enc0["strings"][0][0] or enc1["strings"][2][0] != enc0["strings"][2][0], "the step changed nothing?"
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    fresh = VideoCompressor()
+    fresh.load_state_dict(sd, strict=True)
+    fresh = fresh.cuda().eval()
+    dec = fresh.decode(enc1["strings"], enc1["shapes"], refs)
+    same = torch.equal(dec, enc1["recon"])
+    report(f"encode after a train step, decode in a fresh model: identical reconstruction = {same}; "
+           f"max|d| {float((dec - enc1['recon']).abs().max()):.3e}")
+    assert same, "a fresh decoder loaded from the state_dict does not reproduce the encoder's reconstruction"

@@ -226,3 +226,57 @@ def test_bitstream_container_layout():
     assert bitstream.read_records(big, 1)[0][0] == b"x" * 65535
     with pytest.raises(ValueError):
         bitstream.read_records(io.BytesIO(raw[:-1]), 3)
+
+
+def test_checkpoint_with_filled_coder_tables_loads_strict():
+    """a checkpoint saved after `update()` carries the CDF buffers filled; like compressai's load_state_dict the module
+    resizes its (empty) buffers, so `load_state_dict(strict=True)` (tools/predict.py:150) works both ways"""
+    from oracle.tdvc_ref import coder as oc
+    from tdvc_amd.model import coder as dc
+    a = oc.MVCoder(N=128)
+    a.update(force=True)
+    sd = a.state_dict()
+    assert sd["gaussian_conditional._quantized_cdf"].numel() > 0
+    for cls in (oc.MVCoder, dc.MVCoder):
+        b = cls(N=128)
+        b.load_state_dict(sd, strict=True)
+        assert torch.equal(b.gaussian_conditional._quantized_cdf, sd["gaussian_conditional._quantized_cdf"])
+        assert torch.equal(b.entropy_bottleneck._offset, sd["entropy_bottleneck._offset"])
+        c = cls(N=128)                                     # and back: an un-updated checkpoint into an updated module
+        b.load_state_dict(c.state_dict(), strict=True)
+        assert b.gaussian_conditional._offset.numel() == 0
+
+
+def test_bench_self_launch_forwards_arguments(monkeypatch):
+    """`python bench.py --gpus 2` without a launcher: the ranks are started as fresh children under torch.distributed.run
+    (one per GPU, 127.0.0.1 rendezvous) with the caller's arguments, and the launcher's exit code is the process's."""
+    import importlib.util
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--mode", "train"])
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 7                                # a failing child makes bench.py fail
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "2", "--steps", "3", "--warmup", "1", "--mode", "train"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # under a launcher whose world size disagrees with --gpus the run refuses instead of measuring something else
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert "WORLD_SIZE=4" in str(ex.value.code)

@@ -83,3 +83,45 @@ def test_forward_train_mode_runs(small_coder):
     out = m(torch.randn(1, 64, 64, 64) * 0.5)
     assert out["x_hat"].shape == (1, 64, 64, 64) and float(m.aux_loss()) > 0
     m.eval()
+
+
+def test_lower_bound_backward_rule():
+    """compressai `LowerBoundFunction` (ops/bound_ops.py): forward max(x, bound); the gradient passes where
+    x >= bound OR grad < 0.  Hand-computed vector at, below and above the bound, for the oracle's LowerBound and for
+    the product's parameter-space twin (GDN beta / gamma chain)."""
+    from tdvc_amd.model import coder as dc
+    x0 = [0.05, 0.05, 0.11, 0.11, 0.20, 0.20]          # below, below, at, at, above, above   (bound 0.11)
+    g0 = [-2.0, 3.0, -2.0, 3.0, -2.0, 3.0]
+    want = [-2.0, 0.0, -2.0, 3.0, -2.0, 3.0]           # below the bound only the negative gradient passes
+    for LB in (oc.LowerBound, dc.LowerBound):
+        lb = LB(0.11)
+        x = torch.tensor(x0, requires_grad=True)
+        y = lb(x)
+        assert torch.allclose(y, torch.tensor([0.11, 0.11, 0.11, 0.11, 0.20, 0.20]))
+        y.backward(torch.tensor(g0))
+        assert x.grad.tolist() == want, (LB.__module__, x.grad.tolist())
+    # the Gaussian conditional's two bounds, hand-derived: bits = -log2 max(lik, 1e-9), lik = Phi((.5-v)/s) - Phi((-.5-v)/s),
+    # s = max(scale, 0.11).  A scale of 0.05 (below the bound) with the sample one bin off the mean: d bits / d s < 0
+    # (a wider Gaussian would code it cheaper), so the gradient must reach `scale`; with the sample ON the mean the
+    # gradient is positive and must be blocked.
+    gc = oc.GaussianConditional()
+    sc = torch.tensor([0.05, 0.05, 0.5], requires_grad=True)
+    y = torch.tensor([1.0, 0.0, 1.0])
+    _, lik = gc(y, sc, torch.zeros(3), False)
+    (-torch.log2(lik)).sum().backward()
+    assert sc.grad[0] < 0 and sc.grad[1] == 0 and sc.grad[2] != 0, sc.grad
+    s, v = 0.11, 1.0                                     # element 0 by hand (fp64), scale pinned at the bound
+    import math
+    a, b = (0.5 - v) / s, (-0.5 - v) / s
+    Phi = lambda t: 0.5 * math.erfc(-t / math.sqrt(2))
+    pdf = lambda t: math.exp(-0.5 * t * t) / math.sqrt(2 * math.pi)
+    lik0 = Phi(a) - Phi(b)
+    want0 = -(1.0 / (max(lik0, 1e-9) * math.log(2))) * (b * pdf(b) - a * pdf(a)) / s
+    assert abs(float(sc.grad[0]) - want0) <= 2e-3 * abs(want0), (float(sc.grad[0]), want0)
+    # likelihood floor: a sample 40 sigma out has lik < 1e-9; -log2 of the floored value still pushes it back
+    sc2 = torch.tensor([0.5], requires_grad=True)
+    y2 = torch.tensor([20.0], requires_grad=True)
+    _, lik2 = gc(y2, sc2, torch.zeros(1), False)
+    assert float(lik2) == pytest.approx(1e-9)
+    (-torch.log2(lik2)).sum().backward()
+    assert float(y2.grad) >= 0.0 and float(sc2.grad) <= 0.0      # (the tail pdf underflows in fp32: the sign is what is pinned)

@@ -118,7 +118,9 @@ def test_scale_act_res_sub(report):
     assert_close(fm_to_cpu(y), a - b, 1e-3, 1e-3, "a - b", report)
 
 
-@pytest.mark.parametrize("H,W,scale", [(64, 96, 8), (32, 64, 4), (128, 192, 16), (64, 64, 8)])
+# the last three: W (and H) not a multiple of `scale` (floor pooling drops the remainder; the gather blocks of
+# 3 * scale pixels overhang the frame) -- the geometry of the 1080p frame, scale 136 (pnet.py:219-225)
+@pytest.mark.parametrize("H,W,scale", [(64, 96, 8), (32, 64, 4), (128, 192, 16), (64, 64, 8), (96, 160, 12), (88, 120, 11), (100, 150, 12)])
 def test_feature_matching(H, W, scale, report):
     """pool -> 3x3 patch cosine argmax -> block gather -> cosine weight, vs the oracle's
     unfold/bmm/max/gather/fold formulation (pnet.py:219-257)."""
@@ -127,7 +129,8 @@ def test_feature_matching(H, W, scale, report):
     ff = RefFF()
     fin, fref = rnd16(randn(2, 64, H, W, seed=17)), rnd16(randn(2, 64, H, W, seed=18))
     # make some input patches resemble reference patches so the argmax is meaningful
-    fin[:, :, : H // 2] = rnd16(fref[:, :, H // 2: H // 2 + H // 2] + 0.05 * fin[:, :, : H // 2])
+    h2 = H // 2
+    fin[:, :, :h2] = rnd16(fref[:, :, h2: 2 * h2] + 0.05 * fin[:, :, :h2])
     with torch.no_grad():
         ind, out = ff.match(fin, fref, scale)
         cor = F.cosine_similarity(fin, out).unsqueeze(1)
