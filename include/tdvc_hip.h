@@ -103,6 +103,11 @@ int64_t tdvc_conv_packed_bytes(int cout, int cin, int ntaps, int ck);
 int tdvc_pack_conv_weights(const float* w_oihw, int cout, int cin_real, int cin, int kh, int kw,
                            int ntaps, const int8_t* tap_dy, const int8_t* tap_dx, int ck, uint16_t* dst);
 int tdvc_conv2d(const tdvc_conv_desc* d, void* stream);
+/* The fp32 islands: main/model/pnet.py:33-49,57-73 run both coders with autocast OFF (and enabled_amp=False runs the
+ * whole model fp32).  Same descriptor with an fp32 input fmap (C %% 8 == 0) and `w` = the fp32 packing below; fp32
+ * accumulation on v_mfma_f32_32x32x2_f32; aux / residual / output fmaps fp32 or fp16.  tdvc_conv2d forwards here
+ * when d->x.dtype == TDVC_F32, so fixed descriptor chains (tdvc_ar_decode_serial) run in either precision. */
+int tdvc_conv2d_f32(const tdvc_conv_desc* d, void* stream);
 
 /* ---------------------------------------------------------------- deformable conv (motion compensation)
  * Fused modulated deformable 3x3 conv, fp16 NHWC, no column buffer:
@@ -282,6 +287,10 @@ int tdvc_round_symbols(const tdvc_fmap* z, const float* median, int32_t* out, vo
 int tdvc_pack_conv_weights_indexed(const float* w, const int32_t* row_off, const int32_t* chan_off, const int32_t* tap_off,
                                    const uint8_t* row_mask, const uint8_t* chan_mask, const uint8_t* tap_mask,
                                    int cout, int cin, int ntaps, int ck, void* dst, void* stream);
+/* fp32 twin of the packing (same item order, 8 floats per item: 2 x tdvc_conv_packed_bytes bytes) for tdvc_conv2d_f32. */
+int tdvc_pack_conv_weights_indexed_f32(const float* w, const int32_t* row_off, const int32_t* chan_off, const int32_t* tap_off,
+                                       const uint8_t* row_mask, const uint8_t* chan_mask, const uint8_t* tap_mask,
+                                       int cout, int cin, int ntaps, int ck, float* dst, void* stream);
 /* The same for many layers in one launch (after an optimizer step every packed layer follows its parameters).  `jobs`
  * and `block_start` (njobs + 1 prefix sums of tdvc_pack_job_blocks) are DEVICE arrays; a job with bias_src also
  * gathers its bias: bias_dst[i] = bias_src[bias_perm ? bias_perm[i] : i], i < cout. */

@@ -51,7 +51,9 @@ SIGNATURES = {
     "tdvc_conv_packed_bytes": (_i64, [_i, _i, _i, _i]),
     "tdvc_pack_conv_weights": (_i, [_P, _i, _i, _i, _i, _i, _i, _P, _P, _i, _P]),
     "tdvc_conv2d": (_i, [C.POINTER(ConvDesc), _P]),
+    "tdvc_conv2d_f32": (_i, [C.POINTER(ConvDesc), _P]),
     "tdvc_pack_conv_weights_indexed": (_i, [_P] * 7 + [_i] * 4 + [_P, _P]),
+    "tdvc_pack_conv_weights_indexed_f32": (_i, [_P] * 7 + [_i] * 4 + [_P, _P]),
     "tdvc_pack_job_blocks": (_i64, [_i, _i, _i, _i]),
     "tdvc_pack_conv_weights_batch": (_i, [_P, _P, _i, _i, _P]),
     "tdvc_act_backward": (_i, [_FM, _FM, _FM, _i, _f, _FM, _P]),

@@ -10,24 +10,29 @@ namespace {
 __constant__ int8_t kTapDy[12] = {-2, -2, -2, -2, -2, -1, -1, -1, -1, -1, 0, 0};
 __constant__ int8_t kTapDx[12] = {-2, -1, 0, 1, 2, -2, -1, 0, 1, 2, -2, -1};
 
+// T = half_t (default coders) or float (fp32 islands); VT = the 16-byte vector of T (8 halves / 4 floats)
+template <typename T, typename VT>
 __global__ void ar_gather_kernel(FMap yh, FMap pr, const int32_t* pos, int npos, FMap x1, FMap pc) {
-  const int M8 = yh.C / 8;                        // 16-byte chunks per position
-  const int per = 12 * M8 + pr.C / 8;             // chunks to move per position
+  constexpr int VE = 16 / sizeof(T);              // elements per 16-byte chunk
+  const int MV = yh.C / VE;                       // 16-byte chunks per position
+  const int per = 12 * MV + pr.C / VE;            // chunks to move per position
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)npos * per) return;
   const int k = (int)(i / per), u = (int)(i % per);
   const int h = pos[2 * k], w = pos[2 * k + 1];
-  if (u < 12 * M8) {
-    const int t = u / M8, c8 = u % M8;
+  if (u < 12 * MV) {
+    const int t = u / MV, cv = u % MV;
     const int yy = h + kTapDy[t], xx = w + kTapDx[t];
-    half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    VT v;
+#pragma unroll
+    for (int j = 0; j < VE; ++j) v[j] = (T)0.f;
     if (yy >= 0 && xx >= 0 && xx < yh.W)
-      v = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(yh.p) + ((long)yy * yh.W + xx) * yh.sp + c8 * 8);
-    *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(x1.p) + (long)k * x1.sp + (t * M8 + c8) * 8) = v;
+      v = *reinterpret_cast<const VT*>(reinterpret_cast<const T*>(yh.p) + ((long)yy * yh.W + xx) * yh.sp + cv * VE);
+    *reinterpret_cast<VT*>(reinterpret_cast<T*>(x1.p) + (long)k * x1.sp + (t * MV + cv) * VE) = v;
   } else {
-    const int c8 = u - 12 * M8;
-    const half8 v = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(pr.p) + ((long)h * pr.W + w) * pr.sp + c8 * 8);
-    *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(pc.p) + (long)k * pc.sp + c8 * 8) = v;
+    const int cv = u - 12 * MV;
+    const VT v = *reinterpret_cast<const VT*>(reinterpret_cast<const T*>(pr.p) + ((long)h * pr.W + w) * pr.sp + cv * VE);
+    *reinterpret_cast<VT*>(reinterpret_cast<T*>(pc.p) + (long)k * pc.sp + cv * VE) = v;
   }
 }
 
@@ -51,7 +56,8 @@ __global__ void ar_quantize_kernel(FMap y, FMap gp, const int32_t* pos, int npos
   int q;
   if (sym_in) q = sym_in[o];
   else q = (int)rintf(reinterpret_cast<const float*>(y.p)[((long)h * y.W + w) * y.sp + c] - mean);
-  reinterpret_cast<half_t*>(yh.p)[((long)h * yh.W + w) * yh.sp + c] = (half_t)((float)q + mean);
+  if (yh.f32) reinterpret_cast<float*>(yh.p)[((long)h * yh.W + w) * yh.sp + c] = (float)q + mean;
+  else reinterpret_cast<half_t*>(yh.p)[((long)h * yh.W + w) * yh.sp + c] = (half_t)((float)q + mean);
   sym[o] = q;
   idx[o] = scale_index(scale, table, ntable);
 }
@@ -84,12 +90,18 @@ inline dim3 g1(long n) { return dim3((unsigned)((n + 255) / 256)); }
 extern "C" int tdvc_ar_gather(const tdvc_fmap* y_hat, const tdvc_fmap* params, const int32_t* pos, int npos,
                               const tdvc_fmap* x1, const tdvc_fmap* pc, void* stream) {
   TDVC_CHECK(y_hat && params && pos && x1 && pc && npos >= 1, "tdvc_ar_gather: null / empty");
-  TDVC_CHECK(fmap_ok16(*y_hat) && fmap_ok16(*params) && fmap_ok16(*x1) && fmap_ok16(*pc), "tdvc_ar_gather: fp16 fmaps expected");
+  const bool f32 = y_hat->dtype == TDVC_F32;
+  auto okv = [&](const tdvc_fmap& f) {               // all four of one dtype; 16-byte chunks
+    return f32 ? (fmap_ok32(f) && (f.C % 4) == 0 && (f.sp % 4) == 0 && aligned16(f.p)) : fmap_ok16(f);
+  };
+  TDVC_CHECK(okv(*y_hat) && okv(*params) && okv(*x1) && okv(*pc), "tdvc_ar_gather: four fp16 fmaps, or four fp32 fmaps (fp32 islands), expected");
   TDVC_CHECK(y_hat->N == 1 && params->N == 1 && params->H == y_hat->H && params->W == y_hat->W, "tdvc_ar_gather: one image at a time, params geometry must match y_hat");
   TDVC_CHECK(x1->C == 12 * y_hat->C && x1->W >= npos && x1->H == 1 && pc->C >= params->C && pc->W >= npos && pc->H == 1,
              "tdvc_ar_gather: x1 must be (1,1,>=npos,12*M), pc (1,1,>=npos,>=2M)");
-  const long total = (long)npos * (12 * y_hat->C / 8 + params->C / 8);
-  hipLaunchKernelGGL(ar_gather_kernel, g1(total), dim3(256), 0, ST(stream), to_dev(*y_hat), to_dev(*params), pos, npos, to_dev(*x1), to_dev(*pc));
+  const int ve = f32 ? 4 : 8;
+  const long total = (long)npos * (12 * y_hat->C / ve + params->C / ve);
+  if (f32) hipLaunchKernelGGL((ar_gather_kernel<float, f32x4>), g1(total), dim3(256), 0, ST(stream), to_dev(*y_hat), to_dev(*params), pos, npos, to_dev(*x1), to_dev(*pc));
+  else hipLaunchKernelGGL((ar_gather_kernel<half_t, half8>), g1(total), dim3(256), 0, ST(stream), to_dev(*y_hat), to_dev(*params), pos, npos, to_dev(*x1), to_dev(*pc));
   return tdvc_launch_status("tdvc_ar_gather");
 }
 
@@ -98,7 +110,8 @@ extern "C" int tdvc_ar_quantize(const tdvc_fmap* y, const tdvc_fmap* gp, const i
                                 const tdvc_fmap* y_hat, int32_t* symbols, int32_t* indexes, void* stream) {
   TDVC_CHECK(gp && pos && scale_table && y_hat && symbols && indexes && npos >= 1 && ntable >= 2, "tdvc_ar_quantize: null / empty");
   TDVC_CHECK(symbols_in || (y && fmap_ok32(*y)), "tdvc_ar_quantize: need y (encoder) or symbols_in (decoder)");
-  TDVC_CHECK(fmap_ok32(*gp) && fmap_ok16(*y_hat) && y_hat->N == 1 && gp->C >= 2 * y_hat->C && gp->W >= npos, "tdvc_ar_quantize: bad gp / y_hat");
+  TDVC_CHECK(fmap_ok32(*gp) && (y_hat->dtype == TDVC_F32 ? fmap_ok32(*y_hat) : fmap_ok16(*y_hat)) && y_hat->N == 1 && gp->C >= 2 * y_hat->C && gp->W >= npos,
+             "tdvc_ar_quantize: bad gp / y_hat");
   FMap yd = y ? to_dev(*y) : to_dev(*y_hat);
   yd.C = y_hat->C; yd.W = y_hat->W; yd.H = y_hat->H;
   hipLaunchKernelGGL(ar_quantize_kernel, g1((long)npos * y_hat->C), dim3(256), 0, ST(stream), yd, to_dev(*gp), pos, npos, scale_table, ntable,

@@ -40,11 +40,18 @@ __device__ __forceinline__ void epilogue4(const ConvParams& p, int n, int oy, in
     PW = 2 * p.Wo;
   }
   if (p.gdn) {
-    const half_t* ap = reinterpret_cast<const half_t*>(p.aux.p) + (long)n * p.aux.sn + ((long)oy * p.Wo + ox) * p.aux.sp + co;
-    const half4 a4 = *reinterpret_cast<const half4*>(ap);
+    float a[4];
+    if (p.aux.f32) {                       // fp32 islands (conv_f32): exact 1 / sqrtf like the reference's torch.rsqrt on CPU
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.aux.p) + (long)n * p.aux.sn + ((long)oy * p.Wo + ox) * p.aux.sp + co);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      v[i] = (float)a4[i] * (p.gdn == TDVC_GDN_FWD ? rsqrtf(v[i]) : sqrtf(v[i]));
+      for (int i = 0; i < 4; ++i) v[i] = a4[i] * (p.gdn == TDVC_GDN_FWD ? 1.0f / sqrtf(v[i]) : sqrtf(v[i]));
+    } else {
+      const half4 a4 = *reinterpret_cast<const half4*>(reinterpret_cast<const half_t*>(p.aux.p) + (long)n * p.aux.sn + ((long)oy * p.Wo + ox) * p.aux.sp + co);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = (float)a4[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = a[i] * (p.gdn == TDVC_GDN_FWD ? rsqrtf(v[i]) : sqrtf(v[i]));
+    }
   }
   if (p.round16) {
 #pragma unroll
@@ -68,9 +75,16 @@ __device__ __forceinline__ void epilogue4(const ConvParams& p, int n, int oy, in
     }
   }
   if (p.res2.p && pc < p.res2.C) {
-    const half4 r4 = *reinterpret_cast<const half4*>(reinterpret_cast<const half_t*>(p.res2.p) + (long)n * p.res2.sn + opix * p.res2.sp + pc);
+    if (p.res2.f32) {
+      const float* rp = reinterpret_cast<const float*>(p.res2.p) + (long)n * p.res2.sn + opix * p.res2.sp + pc;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] += (float)r4[i];
+      for (int i = 0; i < 4; ++i)
+        if (pc + i < p.res2.C) v[i] += rp[i];
+    } else {
+      const half4 r4 = *reinterpret_cast<const half4*>(reinterpret_cast<const half_t*>(p.res2.p) + (long)n * p.res2.sn + opix * p.res2.sp + pc);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += (float)r4[i];
+    }
   }
   if (p.out_mode == TDVC_OUT_NCHW_F32) {
     float* yp = reinterpret_cast<float*>(p.y.p);

@@ -252,6 +252,10 @@ static thread_local char g_last_kernel[48] = "";
 
 extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
   TDVC_CHECK(d, "tdvc_conv2d: null descriptor");
+  if (d->x.dtype == TDVC_F32) {           // fp32 islands (pnet.py:33,57): fp32 activations + fp32 packing -> conv_f32.hip
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_f32");
+    return tdvc_conv2d_f32(d, stream);
+  }
   TDVC_CHECK(fmap_ok16(d->x), "tdvc_conv2d: input must be an fp16 fmap with C,sp %% 8 == 0 and 16-byte aligned");
   TDVC_CHECK(d->w && aligned16(d->w), "tdvc_conv2d: weights null/unaligned");
   TDVC_CHECK(d->stride == 1 || d->stride == 2, "tdvc_conv2d: stride %d unsupported", d->stride);

@@ -299,7 +299,7 @@ class Cheng2020Anchor(nn.Module, PackCache):
 
     # -- transforms ------------------------------------------------------------------------
     def run_g_a(self, x: FM):
-        """-> (y fp32 FM, y fp16 FM)"""
+        """-> (y fp32 FM, y FM for h_a: fp16 by default, the fp32 y itself when x is fp32 = the fp32-island mode)"""
         g = self.g_a
         t = g[0].run(x)
         t = g[1].run(t)
@@ -310,8 +310,12 @@ class Cheng2020Anchor(nn.Module, PackCache):
         t = g[6].run(t)
         # y feeds round(): keep the last analysis conv + SE scaling in fp32 (an fp16 store here
         # costs ~0.2 % symbol flips against the fp32 reference)
+        f32 = x.f32
         t = ops.conv(t, pk_conv(self, "ga7", g[7]), out_dtype=torch.float32)
         y32 = FM.empty(t.N, t.H, t.W, t.C, dtype=torch.float32, device=t.t.device)
+        if f32:
+            g[8].run(t, out=y32)
+            return y32, y32
         y16 = FM.empty(t.N, t.H, t.W, t.C, device=t.t.device)
         g[8].run(t, out=y32, out2=y16)
         return y32, y16
@@ -324,7 +328,9 @@ class Cheng2020Anchor(nn.Module, PackCache):
         t = g[5].run(t)
         for i in range(6, 9):
             t = g[i].run(t)
-        return ops.conv(t, pk_conv(self, "gs9", g[9][0], shuffle=True), out=out, res=res)
+        # x_hat re-enters an autocast region (pnet.py:51,75): fp16 whatever the coder's precision; the fused `+ res` is
+        # prediction + recon_res of pnet.py:76, summed in fp32 and rounded once
+        return ops.conv(t, pk_conv(self, "gs9", g[9][0], shuffle=True), out=out, res=res, out_dtype=torch.float16)
 
     def run_h_a(self, y16: FM) -> FM:
         h = self.h_a
@@ -360,14 +366,25 @@ class Cheng2020Anchor(nn.Module, PackCache):
         return self._pk("ctx", build)
 
     # -- forward (`main/model/pnet.py:34,58`) ------------------------------------------------
-    def run(self, x: FM, training: bool, out: FM | None = None, res: FM | None = None, trace=None, noise=None):
-        """x: (B,H,W,64) fp16.  Returns (x_hat FM [+res], bits tensor (2,) float64 = [y, z])."""
+    def _as_f32(self, x: FM) -> FM:
+        """`estmv.float()` / `input_residual.float()` of pnet.py:34,58: the fp32 island's input"""
+        return x if x.f32 else ops.copy_cast(x, FM.empty(x.N, x.H, x.W, x.C, dtype=torch.float32, device=x.t.device))
+
+    def run(self, x: FM, training: bool, out: FM | None = None, res: FM | None = None, trace=None, noise=None, f32=False):
+        """x: (B,H,W,64) fp16.  Returns (x_hat FM [+res], bits tensor (2,) float64 = [y, z]).
+        `f32`: run the coder as the reference's fp32 island (pnet.py:33-49: autocast off, `estmv.float()`): fp32
+        activations and weights on the fp32 MFMA form of every conv; inference only."""
         dev = x.t.device
+        if f32:
+            if training:
+                raise RuntimeError("the fp32-island mode has no backward: train with the default (fp16-in / fp32-accumulate) coders")
+            x = self._as_f32(x)
+        adt = torch.float32 if f32 else torch.float16          # activation dtype inside the coder
         y32, y16 = self.run_g_a(x)
         z = self.run_h_a(y16)
         B, h, w, M = y32.N, y32.H, y32.W, self.M
         bits = torch.zeros(2, dtype=torch.float64, device=dev)
-        z_hat = FM.empty(z.N, z.H, z.W, z.C, device=dev)
+        z_hat = FM.empty(z.N, z.H, z.W, z.C, dtype=adt, device=dev)
         nz = ny = nl = None
         if training:
             # three independent U(-1/2, 1/2) draws, as compressai: factorised prior, y_hat, Gaussian likelihood
@@ -377,9 +394,9 @@ class Cheng2020Anchor(nn.Module, PackCache):
             ny = noise.get("y") or FM(torch.rand((B, h, w, M), device=dev) - 0.5)
             nl = noise.get("y_lik") or FM(torch.rand((B, h, w, M), device=dev) - 0.5)
         ops.eb_forward(z, self.entropy_bottleneck.packed_params(), z_hat, bits[1:2], noise=nz)
-        pcat = FM.empty(B, h, w, 4 * M, device=dev)             # [h_s params | context]
+        pcat = FM.empty(B, h, w, 4 * M, dtype=adt, device=dev)  # [h_s params | context]
         self.run_h_s(z_hat, out=pcat.ch(0, 2 * M))
-        y_hat = ops.quantize(y32, FM.empty(B, h, w, M, device=dev), noise=ny)
+        y_hat = ops.quantize(y32, FM.empty(B, h, w, M, dtype=adt, device=dev), noise=ny)
         ops.conv(y_hat, self.ctx_conv(), out=pcat.ch(2 * M, 2 * M))
         gp = self.run_entropy_parameters(pcat)
         ops.gc_forward(y32, gp, bits[0:1], noise=nl)
@@ -486,29 +503,33 @@ class Cheng2020Anchor(nn.Module, PackCache):
         return self.run_entropy_parameters(v(pc, 0, 4 * self.M))
 
     @torch.no_grad()
-    def compress(self, x: FM):
-        """-> {"strings": [y_strings, z_strings], "shape": (h, w)} like compressai's compress()"""
+    def compress(self, x: FM, f32=False):
+        """-> {"strings": [y_strings, z_strings], "shape": (h, w)} like compressai's compress()
+        (`f32`: the fp32-island mode, see run())"""
         dev = x.t.device
         ebt, gct, table = self._coder_tables()
         M = self.M
+        if f32:
+            x = self._as_f32(x)
+        adt = torch.float32 if f32 else torch.float16
         y32, y16 = self.run_g_a(x)
         z = self.run_h_a(y16)
         B, H, W = y32.N, y32.H, y32.W
         med = self.entropy_bottleneck.quantiles.detach()[:, 0, 1].float().contiguous()
         zsym = ops.round_symbols(z, med)                                           # (B, h, w, C) int32
-        z_hat = FM((zsym.float() + med).half())
-        params = FM.empty(B, H, W, 2 * M, device=dev)
+        z_hat = FM((zsym.float() + med).to(adt))
+        params = FM.empty(B, H, W, 2 * M, dtype=adt, device=dev)
         self.run_h_s(z_hat, out=params)
         zs = zsym.permute(0, 3, 1, 2).contiguous().cpu().numpy()                   # compressai order (C, h, w)
         zidx = np.broadcast_to(np.arange(M, dtype=np.int32)[:, None, None], zs.shape[1:])
         z_strings = [ops.rans_encode(zs[b], zidx, ebt) for b in range(B)]
         steps = self.wavefront_steps(H, W)
         flat = torch.tensor([p for st in steps for p in st], dtype=torch.int32, device=dev)
-        x1 = FM.empty(1, 1, H, 12 * M, device=dev)
-        pc = FM.empty(1, 1, H, 4 * M, device=dev)
+        x1 = FM.empty(1, 1, H, 12 * M, dtype=adt, device=dev)
+        pc = FM.empty(1, 1, H, 4 * M, dtype=adt, device=dev)
         y_strings, dbg = [], []
         for b in range(B):
-            y_hat = FM.zeros(1, H, W, M, device=dev)
+            y_hat = FM.zeros(1, H, W, M, dtype=adt, device=dev)
             sym = torch.zeros((H, W, M), dtype=torch.int32, device=dev)
             idx = torch.zeros((H, W, M), dtype=torch.int32, device=dev)
             o = 0
@@ -523,10 +544,11 @@ class Cheng2020Anchor(nn.Module, PackCache):
         return {"strings": [y_strings, z_strings], "shape": (z.H, z.W), "_debug": dbg}
 
     @torch.no_grad()
-    def decompress(self, strings, shape, synth=True):
+    def decompress(self, strings, shape, synth=True, f32=False):
         """strings as returned by compress(); serial raster-order context decoding (the stream order of
-        compressai's bitstream).  -> {"x_hat": FM, "y_hat": FM}"""
+        compressai's bitstream).  -> {"x_hat": FM, "y_hat": FM}.  `f32` must match the encoder's mode."""
         dev = self.context_prediction.weight.device
+        adt = torch.float32 if f32 else torch.float16
         ebt, gct, table = self._coder_tables()
         M = self.M
         zh, zw = shape
@@ -536,12 +558,12 @@ class Cheng2020Anchor(nn.Module, PackCache):
         zidx = np.broadcast_to(np.arange(M, dtype=np.int32)[:, None, None], (M, zh, zw))
         zs = np.stack([ops.RansDecoder(s).decode(zidx, ebt).reshape(M, zh, zw) for s in strings[1]])
         zsym = torch.from_numpy(zs).to(dev).permute(0, 2, 3, 1).contiguous()
-        z_hat = FM((zsym.float() + med).half())
-        params = FM.empty(B, H, W, 2 * M, device=dev)
+        z_hat = FM((zsym.float() + med).to(adt))
+        params = FM.empty(B, H, W, 2 * M, dtype=adt, device=dev)
         self.run_h_s(z_hat, out=params)
-        x1 = FM.empty(1, 1, 1, 12 * M, device=dev)
-        pc = FM.empty(1, 1, 1, 4 * M, device=dev)
-        y_hat_all = FM.zeros(B, H, W, M, device=dev)
+        x1 = FM.empty(1, 1, 1, 12 * M, dtype=adt, device=dev)
+        pc = FM.empty(1, 1, 1, 4 * M, dtype=adt, device=dev)
+        y_hat_all = FM.zeros(B, H, W, M, dtype=adt, device=dev)
         sym = torch.zeros((H, W, M), dtype=torch.int32, device=dev)
         idx = torch.zeros((H, W, M), dtype=torch.int32, device=dev)
         # the per-position chain as fixed conv descriptors over fixed buffers: context conv (1x1 over the gathered
@@ -550,8 +572,8 @@ class Cheng2020Anchor(nn.Module, PackCache):
         e = self.entropy_parameters
         v = lambda fm, c0, C_: FM(fm.t, c0, 1, C_)
         d0, _, _, _, _, _ = ops.conv_desc(v(x1, 0, x1.C), self._ctx_1x1(), out=v(pc, 2 * M, 2 * M))
-        t0 = FM.empty(1, 1, 1, ops.pad8(e[0].out_channels), device=dev)
-        t1 = FM.empty(1, 1, 1, ops.pad8(e[2].out_channels), device=dev)
+        t0 = FM.empty(1, 1, 1, ops.pad8(e[0].out_channels), dtype=adt, device=dev)
+        t1 = FM.empty(1, 1, 1, ops.pad8(e[2].out_channels), dtype=adt, device=dev)
         gp = FM.empty(1, 1, 1, 2 * M, dtype=torch.float32, device=dev)
         d1, _, _, _, _, _ = ops.conv_desc(v(pc, 0, 4 * M), pk_conv(self, "ep0", e[0]), out=t0, **LR)
         d2, _, _, _, _, _ = ops.conv_desc(t0, pk_conv(self, "ep2", e[2]), out=t1, **LR)

@@ -79,7 +79,7 @@ class SELayer(nn.Module, PackCache):
         return ops.se_gate(x, self.params())
 
     def run(self, x: FM, out: FM | None = None, act=ACT_NONE, slope=0.0, res: FM | None = None, out2: FM | None = None):
-        out = FM.empty(x.N, x.H, x.W, x.C, device=x.t.device) if out is None else out
+        out = FM.empty(x.N, x.H, x.W, x.C, dtype=x.t.dtype, device=x.t.device) if out is None else out
         return ops.scale_act_res(x, out, gate=self.gate(x), act=act, slope=slope, res=res, out2=out2)
 
 

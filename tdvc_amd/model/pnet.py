@@ -20,8 +20,15 @@ from .modules import FeaExtra, FeatureFix, LoopFilter, MCNet, OffsetGen
 
 
 class VideoCompressor(nn.Module):
+    fp32_islands_supported = True
+
     def __init__(self):
         super().__init__()
+        # the reference keeps both coders outside autocast (pnet.py:33,57).  Default here: fp16-in / fp32-accumulate coders
+        # (the 30 fps path); `enabled_amp=False` in forward(), or this flag for encode() / decode(), runs them as true fp32
+        # islands (fp32 activations + weights on v_mfma_f32_32x32x2_f32): symbols and byte streams then equal the fp32 CPU
+        # reference's on identical coder inputs (tests/test_entropy_coding_gpu.py)
+        self.coder_fp32 = False
         self.mvCoder = MVCoder(N=128)
         self.resCoder = ResCoder(N=128)
         self.extra_fea = FeaExtra(2)
@@ -50,6 +57,14 @@ class VideoCompressor(nn.Module):
         noise = noise or {}            # test hook: {"mv": {...}, "res": {...}} of fp32 FMs replaces the coders' training-mode draws
         if not (input_image.is_cuda and refer_frames.is_cuda):
             raise RuntimeError("tdvc_amd.VideoCompressor runs on a HIP device only (no CPU fallback)")
+        f32 = (not enabled_amp) or self.coder_fp32
+        if f32 and self.training:
+            if not self.__dict__.get("_warned_fp32_train"):
+                import warnings
+                warnings.warn("tdvc_amd: the fp32-island coders are an inference / coding mode; training runs the default "
+                              "fp16-in / fp32-accumulate coders (enabled_amp=False ignored in .train())")
+                self.__dict__["_warned_fp32_train"] = True
+            f32 = False
         training = self.training       # noise quantisation, scale-8 matching, 5-tuple return (pnet.py:80-83); gradients
         # come from the tape of tdvc_amd/autograd.py (`with autograd.record(): model(...)`), not from torch.autograd
         B, _, H, W = input_image.shape
@@ -77,11 +92,11 @@ class VideoCompressor(nn.Module):
             estmv = self.motion_est.run(feats, cur32, ref32)
 
             tr_mv = {} if trace is not None else None
-            mv_hat, mv_bits = self.mvCoder.run(estmv, training=training, trace=tr_mv, noise=noise.get("mv"))
+            mv_hat, mv_bits = self.mvCoder.run(estmv, training=training, trace=tr_mv, noise=noise.get("mv"), f32=f32)
             coded = {}
             if is_compress:                                      # pnet.py:45-49
                 self.mvCoder.update(force=True)
-                coded["mv"] = self.mvCoder.compress(estmv)
+                coded["mv"] = self.mvCoder.compress(estmv, f32=f32)
 
             xt = FM.empty(B, H, W, 256, device=dev)                      # 4 frames x 64 ch
             pred1 = self.mcnet.run(mv_hat, feats, xt.ch(192, 64))
@@ -90,10 +105,10 @@ class VideoCompressor(nn.Module):
             resid = ops.scale_act_res(f_cur, FM.empty(B, H, W, 64, device=dev), res=pred, res_sign=-1.0)
 
             tr_res = {} if trace is not None else None
-            recon_f, res_bits = self.resCoder.run(resid, training=training, res=pred, trace=tr_res, noise=noise.get("res"))
+            recon_f, res_bits = self.resCoder.run(resid, training=training, res=pred, trace=tr_res, noise=noise.get("res"), f32=f32)
             if is_compress:                                      # pnet.py:69-73
                 self.resCoder.update(force=True)
-                coded["res"] = self.resCoder.compress(resid)
+                coded["res"] = self.resCoder.compress(resid, f32=f32)
                 # the reference computes these and drops them (pnet.py:49,73); kept for inspection
                 self.last_strings = {k: v["strings"] for k, v in coded.items()}
                 self.last_ac_bpp = {k: sum(len(s[0]) for s in v["strings"]) * 8.0 / npx_ for k, v in coded.items()}
@@ -148,13 +163,14 @@ class VideoCompressor(nn.Module):
         estmv = self.motion_est.run(feats, ops.from_nchw(x, Cpad=4, dtype=torch.float32), ops.from_nchw(last, Cpad=4, dtype=torch.float32))
         self.mvCoder.update()
         self.resCoder.update()
-        mv = self.mvCoder.compress(estmv)
+        f32 = self.coder_fp32
+        mv = self.mvCoder.compress(estmv, f32=f32)
         cat = lambda dbg: FM(torch.cat([d["y_hat"].t for d in dbg], 0))
         out = {}
 
         def res_y_hat(pred):
             resid = ops.scale_act_res(f_cur, FM.empty(B, H, W, 64, device=dev), res=pred, res_sign=-1.0)
-            out["res"] = self.resCoder.compress(resid)
+            out["res"] = self.resCoder.compress(resid, f32=f32)
             return cat(out["res"]["_debug"])
         recon = self._reconstruct(cat(mv["_debug"]), res_y_hat, feats, refs8, iframe8)
         rs = out["res"]
@@ -168,6 +184,7 @@ class VideoCompressor(nn.Module):
         B, H, W, dev, refs8, last, iframe8, feats = self._prepare(refer_frames)
         self.mvCoder.update()
         self.resCoder.update()
-        mv = self.mvCoder.decompress([strings[0], strings[1]], shapes[0])
-        return self._reconstruct(mv["y_hat"], lambda pred: self.resCoder.decompress([strings[2], strings[3]], shapes[1], synth=False)["y_hat"],
+        f32 = self.coder_fp32
+        mv = self.mvCoder.decompress([strings[0], strings[1]], shapes[0], f32=f32)
+        return self._reconstruct(mv["y_hat"], lambda pred: self.resCoder.decompress([strings[2], strings[3]], shapes[1], synth=False, f32=f32)["y_hat"],
                                  feats, refs8, iframe8)

@@ -142,10 +142,18 @@ class PackedConv:
     param_w: torch.Tensor | None = None    # the nn.Parameters that own wsrc / bsrc (gradient accumulators live on them)
     param_b: torch.Tensor | None = None
     owner: object | None = None            # module that maps this layer's weight gradient to its own parameters (GDN)
+    w32: torch.Tensor | None = None        # fp32 twin of `w` for the fp32 islands (conv_f32.hip), packed on first use
+
+    def packed_f32(self) -> torch.Tensor:
+        """the same fragment order as `w`, as floats (tdvc_pack_conv_weights_indexed_f32)"""
+        if self.w32 is None:
+            self.w32 = _pack_from_tables_f32(self.wsrc, self.tables)
+        return self.w32
 
     def repack(self):
         """re-pack from the (updated) fp32 parameters: one kernel launch, plus the bias gather"""
         _pack_from_tables(self.wsrc, self.tables, self.w)
+        self.w32 = None
         if self.bsrc is not None:
             b = self.bsrc.detach().float()
             self.bias[:self.cout] = b[torch.from_numpy(convpack.shuffle_perm(self.cout)).to(b.device)] if self.shuffle else b
@@ -192,6 +200,19 @@ def _pack_from_tables(wsrc: torch.Tensor, tb: convpack.PackTables, dst: torch.Te
     L.check(lib.tdvc_pack_conv_weights_indexed(w.data_ptr(), tb.row_off.data_ptr(), tb.chan_off.data_ptr(), tb.tap_off.data_ptr(),
                                                tb.row_mask.data_ptr(), tb.chan_mask.data_ptr(), tb.tap_mask.data_ptr(),
                                                tb.cout, tb.cin, len(tb.taps), tb.ck, dst.data_ptr(), _stream()), "pack_conv_weights_indexed")
+    return dst
+
+
+def _pack_from_tables_f32(wsrc: torch.Tensor, tb: convpack.PackTables) -> torch.Tensor:
+    lib = L.lib()
+    nbytes = lib.tdvc_conv_packed_bytes(tb.cout, tb.cin, len(tb.taps), tb.ck)
+    assert nbytes > 0
+    w = wsrc.detach()
+    assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
+    dst = torch.empty(nbytes // 2, dtype=torch.float32, device=w.device)      # 8 floats where the fp16 blob has 8 halves
+    L.check(lib.tdvc_pack_conv_weights_indexed_f32(w.data_ptr(), tb.row_off.data_ptr(), tb.chan_off.data_ptr(), tb.tap_off.data_ptr(),
+                                                   tb.row_mask.data_ptr(), tb.chan_mask.data_ptr(), tb.tap_mask.data_ptr(),
+                                                   tb.cout, tb.cin, len(tb.taps), tb.ck, dst.data_ptr(), _stream()), "pack_conv_weights_indexed_f32")
     return dst
 
 
@@ -266,6 +287,8 @@ class PackBatch:
                 break
         L.check(L.lib().tdvc_pack_conv_weights_batch(self.jobs.data_ptr(), self.starts.data_ptr(), len(self.pcs), self.total_blocks, _stream()),
                 "pack_conv_weights_batch")
+        for pc in self.pcs:
+            pc.w32 = None                # fp32 twins (fp32 islands, inference only) are rebuilt from the parameters on next use
 
 
 def _pick_ck(cin, cout, kh, kw, stride, pad):
@@ -336,14 +359,19 @@ def _plain_form(pc: PackedConv) -> PackedConv:
 
 
 def conv_desc(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, res: FM | None = None,
-              res2: FM | None = None, gdn=GDN_NONE, aux: FM | None = None, square=False, out_dtype=torch.float16,
+              res2: FM | None = None, gdn=GDN_NONE, aux: FM | None = None, square=False, out_dtype=None,
               round16=False, nchw_out: torch.Tensor | None = None):
     """the `tdvc_conv_desc` a conv() call would launch, without launching it (native loops re-launch fixed descriptors:
-    `tdvc_ar_decode_serial`).  -> (descriptor, result FM / tensor, Ho, Wo, layer form used, layer as recorded)"""
+    `tdvc_ar_decode_serial`).  -> (descriptor, result FM / tensor, Ho, Wo, layer form used, layer as recorded)
+
+    An fp32 input FM selects the fp32 form of the layer (fp32 weights, v_mfma_f32_32x32x2_f32: the fp32 islands of
+    pnet.py:33,57); `out_dtype=None` allocates the output in the input's dtype."""
     assert x.C == pc.cin, f"conv: input has {x.C} channels, layer packed for {pc.cin}"
     rec_pc = pc                                   # the tape records the layer itself (its dgrad / wgrad forms hang off it)
-    if pc.s2d and x.N * (x.H // 2) * (x.W // 2) <= SMALL_MAP_PIXELS:
-        pc = _plain_form(pc)                      # small maps: the plain stride-2 form runs on the split-K kernel
+    if out_dtype is None:
+        out_dtype = torch.float32 if x.f32 else torch.float16
+    if pc.s2d and (x.f32 or x.N * (x.H // 2) * (x.W // 2) <= SMALL_MAP_PIXELS):
+        pc = _plain_form(pc)                      # small maps: the plain stride-2 form runs on the split-K kernel (fp32: always plain)
     if pc.s2d:
         if x.H % 2 or x.W % 2:
             raise L.TdvcHipError("conv: the space-to-depth stride-2 path needs even H, W")
@@ -353,7 +381,7 @@ def conv_desc(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=
         Wo = (x.W + 2 * pc.pad - pc.kw) // pc.stride + 1
     d = L.ConvDesc()
     d.x = x.desc()
-    d.w = pc.w.data_ptr()
+    d.w = pc.packed_f32().data_ptr() if x.f32 else pc.w.data_ptr()
     d.bias = pc.bias.data_ptr()
     d.cout, d.ntaps = pc.cout, len(pc.taps)
     for i, (dy, dx) in enumerate(pc.taps):
@@ -378,7 +406,7 @@ def conv_desc(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=
         else:
             d.out_mode = OUT_NHWC
             if out is None:
-                out = FM.empty(x.N, Ho, Wo, pc.cout if out_dtype == torch.float32 else pad8(pc.cout),
+                out = FM.empty(x.N, Ho, Wo, pc.cout if (out_dtype == torch.float32 and not x.f32) else pad8(pc.cout),
                                dtype=out_dtype, device=x.t.device)
         d.y = out.desc()
         ret = out
@@ -386,16 +414,18 @@ def conv_desc(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=
 
 
 def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, res: FM | None = None,
-         res2: FM | None = None, gdn=GDN_NONE, aux: FM | None = None, square=False, out_dtype=torch.float16,
+         res2: FM | None = None, gdn=GDN_NONE, aux: FM | None = None, square=False, out_dtype=None,
          round16=False, nchw_out: torch.Tensor | None = None) -> FM | torch.Tensor:
     d, ret, Ho, Wo, pc, rec_pc = conv_desc(x, pc, out, act, slope, res, res2, gdn, aux, square, out_dtype, round16, nchw_out)
+    if x.f32 and TAPE is not None and not _IN_BACKWARD:
+        raise L.TdvcHipError("conv: the fp32 form has no backward (the fp32 islands are an inference / coding mode)")
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         L.check(L.lib().tdvc_conv2d(C.byref(d), _stream()), "conv2d")
         e1.record()
         PROFILE.append(dict(kernel=L.lib().tdvc_last_conv_kernel().decode(),
-                            shape=f"{pc.kh}x{pc.kw} s{pc.stride} {x.C}->{pc.cout} @{x.H}x{x.W}" + (" f32out" if out_dtype != torch.float16 else "") + (" nchw" if nchw_out is not None else ""),
+                            shape=f"{pc.kh}x{pc.kw} s{pc.stride} {x.C}->{pc.cout} @{x.H}x{x.W}" + (" f32out" if out_dtype == torch.float32 else "") + (" nchw" if nchw_out is not None else ""),
                             e0=e0, e1=e1,
                             flops=2.0 * x.N * Ho * Wo * pc.cout * x.C * len(pc.taps),
                             flops_real=(x.N * Ho * Wo * pc.flops_per_px) if pc.s2d else 2.0 * x.N * Ho * Wo * pc.cout * pc.cin_real * len(pc.taps),

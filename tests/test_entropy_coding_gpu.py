@@ -173,3 +173,40 @@ def test_encode_after_train_step_decodes_in_fresh_model(report):
     report(f"encode after a train step, decode in a fresh model: identical reconstruction = {same}; "
            f"max|d| {float((dec - enc1['recon']).abs().max()):.3e}")
     assert same, "a fresh decoder loaded from the state_dict does not reproduce the encoder's reconstruction"
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (128, 192)])
+def test_fp32_island_bitstreams_equal_oracle(coders, H, W, report):
+    """The fp32-island mode (enabled_amp=False / coder_fp32: pnet.py:33-49 runs the coders with autocast off): on identical
+    coder inputs the quantiser symbols, the CDF indexes and therefore BOTH byte strings of compress() equal the fp32 CPU
+    oracle's, the forward's y_hat has no flipped symbol, and decompress() rebuilds the encoder's y_hat."""
+    from tdvc_amd import ops
+    ref, m = coders
+    x = rnd16(randn(1, 64, H, W, seed=31, scale=0.5))
+    xf = to_fm(x, ops)
+    with torch.no_grad():
+        enc_o = ref.compress(x)
+        fo = ref(x)
+    enc = m.compress(xf, f32=True)
+    ys, zs = enc["strings"]
+    d = enc["_debug"][0]
+    sym = d["symbols"].cpu().view(-1)
+    sym_o = torch.tensor(enc_o["_debug"][0]["symbols"])
+    idx_o = torch.tensor(enc_o["_debug"][0]["indexes"])
+    nflip = int((sym != sym_o).sum())
+    nidx = int((d["indexes"].cpu().view(-1) != idx_o).sum())
+    report(f"fp32 islands {H}x{W}: y symbols differing {nflip}/{sym.numel()}, CDF indexes differing {nidx}; "
+           f"y string {len(ys[0])} B (oracle {len(enc_o['strings'][0][0])}), z string {len(zs[0])} B (oracle {len(enc_o['strings'][1][0])})")
+    assert zs[0] == enc_o["strings"][1][0], "z byte string differs from the oracle's compress()"
+    assert ys[0] == enc_o["strings"][0][0], "y byte string differs from the oracle's compress()"
+    tr = {}
+    x_hat, bits = m.run(xf, training=False, trace=tr, f32=True)
+    yh = fm_to_cpu(tr["y_hat"])
+    assert torch.equal(yh, fo["_debug"]["y_hat"]), f"{int((yh != fo['_debug']['y_hat']).sum())} forward y_hat symbols differ"
+    bits_o = torch.stack([(-torch.log2(fo["likelihoods"][k])).sum() for k in ("y", "z")]).double()
+    rel = float(((bits.cpu() - bits_o).abs() / bits_o).max())
+    xe = float((fm_to_cpu(x_hat) - fo["x_hat"]).abs().max())
+    report(f"fp32 islands {H}x{W}: forward bits (y, z) {bits.cpu().tolist()} oracle {bits_o.tolist()} rel err {rel:.2e}; max|x_hat diff| {xe:.2e} (fp16 output)")
+    assert rel < 1e-5
+    dec = m.decompress(enc["strings"], enc["shape"], f32=True)
+    assert torch.equal(dec["y_hat"].t, d["y_hat"].t), "decoder y_hat differs from encoder y_hat (fp32 islands)"

@@ -183,3 +183,94 @@ def test_forward_vs_oracle_1080p(models, report):
     for k in ("pred1", "pred", "resid"):
         assert st[k] < 3e-2, (k, st[k])
     assert st["mv.y_hat_flips"] < 5e-3 and st["res.y_hat_flips"] < 2e-2
+
+
+@pytest.mark.parametrize("H,W", [(128, 192), (256, 256)])
+def test_forward_fp32_islands(models, H, W, report):
+    """`enabled_amp=False`: both coders run as fp32 islands (the reference's pnet.py:33-49,57-73 under any setting).  The
+    AMP regions around them stay fp16-in / fp32-accumulate, so the coders' INPUTS still differ from the fp32 oracle's in
+    the last fp16 bit; what the mode removes is the coders' own rounding: fewer flipped symbols and a smaller rate delta
+    than the default mode on the same frame."""
+    from tdvc_amd.synth import make_gop, ref_list
+    ref, m = models
+    g = make_gop(1234, 2, H, W)
+    refs = ref_list([g[0:1]])
+    tr_o, tr_16, tr_32 = {}, {}, {}
+    with torch.no_grad():
+        ro, bro, bmo = ref(g[1:2], refs, False, trace=tr_o)
+        r16, br16, bm16 = m(g[1:2].cuda(), refs.cuda(), True, trace=tr_16)
+        r32, br32, bm32 = m(g[1:2].cuda(), refs.cuda(), False, trace=tr_32)
+    s16, s32 = _stages(tr_16, tr_o), _stages(tr_32, tr_o)
+    d16 = abs(float(br16 + bm16) - float(bro + bmo))
+    d32 = abs(float(br32 + bm32) - float(bro + bmo))
+    p_o, p_16, p_32 = psnr(ro, g[1:2]), psnr(r16.cpu(), g[1:2]), psnr(r32.cpu(), g[1:2])
+    report(f"[{H}x{W}] fp32 islands vs default: |dbpp| {d32:.5f} vs {d16:.5f} (oracle {float(bro + bmo):.4f} bpp); PSNR oracle {p_o:.4f} "
+           f"fp32-islands {p_32:.4f} default {p_16:.4f}; y_hat flips mv {s32['mv.y_hat_flips']:.2e} vs {s16['mv.y_hat_flips']:.2e}, "
+           f"res {s32['res.y_hat_flips']:.2e} vs {s16['res.y_hat_flips']:.2e}; mv.y rel-L2 {s32['mv.y']:.2e} vs {s16['mv.y']:.2e}")
+    assert abs(p_o - p_32) <= 0.02
+    assert d32 <= 1e-3 + 2.5e-3 * float(bro + bmo)
+    assert s32["mv.y_hat_flips"] <= s16["mv.y_hat_flips"] + 1e-4 and s32["mv.y"] <= s16["mv.y"]
+
+
+def _train_to_operating_point(report, max_iters=600, target_bpp=0.30, lam=256.0):
+    """deterministic TrainSteps on synthetic septuplets (batch 4, 256x256, the tools/train.py sample rule) from the filler
+    initialisation until the training-mode rate is under `target_bpp`; -> (model in eval mode, log of the last step)"""
+    from tdvc_amd.model import VideoCompressor
+    from tdvc_amd.synth import fill_parameters, make_gop, ref_list
+    from tdvc_amd.train import TrainStep
+    torch.manual_seed(1111)                                   # tools/train.py:253-256
+    net = VideoCompressor()
+    fill_parameters(net)
+    net = net.cuda().train()
+    step = TrainStep(net, train_lambda=lam, lr=2e-4, loss_scale=128.0)
+    pool, cursor, ema, log = [], 0, None, None
+    for it in range(max_iters):
+        while len(pool) < 4:
+            gop = make_gop(5000 + cursor, 7, 256, 256)
+            cursor += 1
+            for t in range(1, 7):                             # dataset.py:211-232: refs [I, x(t-3), x(t-2), x(t-1)] with the repeat rules
+                pool.append((gop[t:t + 1], ref_list([gop[k:k + 1] for k in range(0, t)][-4:] if t > 3 else [gop[k:k + 1] for k in range(0, t)])))
+        batch, pool = pool[:4], pool[4:]
+        x = torch.cat([b[0] for b in batch]).cuda()
+        refs = torch.cat([b[1] for b in batch]).cuda()
+        log = step(x, refs)
+        bpp = log["bpp_res"] + log["bpp_mv"]
+        ema = bpp if ema is None else 0.9 * ema + 0.1 * bpp
+        if (it + 1) % 50 == 0:
+            report(f"   train-to-operating-point it {it + 1}: rd_loss {log['rd_loss']:.4f} bpp {bpp:.4f} (ema {ema:.4f}) mse {log['mse']:.2e}")
+        if it >= 100 and ema <= target_bpp:
+            break
+    report(f"   trained {it + 1} iterations (lambda {lam:g}): training-mode bpp ema {ema:.4f}")
+    return net.eval(), ema
+
+
+def test_trained_operating_point_parity(report):
+    """SURVEY 8d's absolute gates at a TRAINED-like operating point instead of the several-bpp filler weights: N
+    deterministic TrainSteps bring the rate to a few tenths of a bpp, the state-dict moves to the fp32 CPU oracle
+    (strict=True), and one P-frame at 256x256 (and 512x768) must agree within |dbpp| <= 0.001 ABSOLUTE and
+    |dPSNR| <= 0.02 dB, in the default (fp16 coders) mode and in the fp32-island mode."""
+    from oracle.tdvc_ref import VideoCompressor as Ref
+    from tdvc_amd.synth import make_gop, ref_list
+    net, ema = _train_to_operating_point(report)
+    ref = Ref().eval()
+    ref.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()}, strict=True)
+    worst = 0.0
+    for (H, W) in ((256, 256), (512, 768)):
+        g = make_gop(1234, 3, H, W)
+        refs_l = [g[0:1]]
+        for t in (1, 2):
+            refs = ref_list(refs_l)
+            with torch.no_grad():
+                ro, bro, bmo = ref(g[t:t + 1], refs, False)
+                r16, br16, bm16 = net(g[t:t + 1].cuda(), refs.cuda(), True)
+                r32, br32, bm32 = net(g[t:t + 1].cuda(), refs.cuda(), False)
+            bo = float(bro + bmo)
+            d16, d32 = float(br16 + bm16) - bo, float(br32 + bm32) - bo
+            p_o, p_16, p_32 = psnr(ro, g[t:t + 1]), psnr(r16.cpu(), g[t:t + 1]), psnr(r32.cpu(), g[t:t + 1])
+            report(f"[trained, {H}x{W} frame {t}] oracle {bo:.5f} bpp {p_o:.4f} dB | default mode dbpp {d16:+.5f} dPSNR {p_16 - p_o:+.4f} | "
+                   f"fp32 islands dbpp {d32:+.5f} dPSNR {p_32 - p_o:+.4f}")
+            assert bo < 0.6, "not a trained-like operating point"
+            assert abs(d16) <= 1e-3 and abs(p_16 - p_o) <= 0.02, "default mode misses the SURVEY 8d gates at the trained operating point"
+            assert abs(d32) <= 1e-3 and abs(p_32 - p_o) <= 0.02, "fp32-island mode misses the SURVEY 8d gates at the trained operating point"
+            worst = max(worst, abs(d16))
+            refs_l.append(ro)
