@@ -26,6 +26,8 @@ int launch_conv_v5(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
 bool conv_v5_eligible(const tdvc_conv_desc* d, int Ho, int Wo);
 int launch_conv_v7(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
 bool conv_v7_eligible(const tdvc_conv_desc* d, const ConvParams& p, int Ho, int Wo);
+int launch_conv_v10(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
+bool conv_v10_eligible(const tdvc_conv_desc* d, const ConvParams& p, int Ho, int Wo);
 int launch_conv_v9(const ConvParams& p, int ck8, int cout_tiles32, int N, hipStream_t st);
 bool conv_v9_eligible(const tdvc_conv_desc* d, int Ho, int Wo, bool v3_ok);
 
@@ -343,6 +345,7 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
   }
   if (conv_v9_eligible(d, Ho, Wo, conv_v3_eligible(d, Ho, Wo))) { chose("conv_mfma_v9"); return launch_conv_v9(p, ck8, tiles, d->x.N, st); }
   if (conv_v5_eligible(d, Ho, Wo)) { chose("conv_mfma_v5"); return launch_conv_v5(p, tiles / 2, d->x.N, st); }
+  if (conv_v10_eligible(d, p, Ho, Wo)) { chose("conv_mfma_v10"); return launch_conv_v10(p, tiles / 2, d->x.N, st); }
   if (conv_v7_eligible(d, p, Ho, Wo)) { chose("conv_mfma_v7"); return launch_conv_v7(p, tiles / 2, d->x.N, st); }
   if (conv_v3_eligible(d, Ho, Wo)) { chose("conv_mfma_v3"); return launch_conv_v3(p, tiles / 2, d->x.N, st); }
   if (conv_v2_eligible(d, Ho, Wo)) { chose("conv_mfma_v2"); return launch_conv_v2(p, 0, tiles / 2, d->x.N, st); }

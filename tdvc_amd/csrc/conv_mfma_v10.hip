@@ -1,0 +1,301 @@
+// conv_mfma_v10 — 3x3, stride 1, pad 1, Cin = 64, Cout >= 64 (the 64->64 / 64->216 convs: the dominant layer class),
+// successor of conv_mfma_v7 for that class.
+//
+// What bounded v7 (rocprofv3 PMC + in-kernel stamps): 39 % MFMA busy; per tile 2 x 6.1k cycles of matrix
+// phase (ideal 2 x 4.6k: the younger wave of each SIMD loses VALU / LDS arbitration and the stage barrier waits for it)
+// + 5.6k of epilogue in which no wave issues an MFMA.  v7's wave computes 64 couts x (2 rows x 32 px): one LDS fragment
+// read per MFMA, and the two waves of a SIMD fight for the issue port.
+//
+// v10 keeps v7's memory system (persistent workgroup per CU, all weights resident in LDS, 16x32-px tiles in 32-channel
+// stages by LDS-DMA into two buffers, XOR-swizzled lane-linear image, counted vmcnt + one barrier per stage, XCD-aware
+// tile walk) and changes the register tile:
+//   * 4 waves, ONE PER SIMD (256 threads, up to 512 VGPRs): a wave owns the matrix pipe of its SIMD, nobody arbitrates;
+//   * each wave computes 64 couts x (4 rows x 32 px): 2 x 4 accumulators (128 registers);
+//   * row reuse: for a fixed (k-half s2, dx) the B fragment of input row ir serves output rows ir, ir-1, ir-2 (dy = 0, 1, 2),
+//     so a group of 24 MFMAs needs 6 A reads (3 dy x 2 mt) + 6 B reads (input rows 0..5): 0.5 LDS reads per MFMA
+//     (v7: 1.0) and half the address arithmetic; the next group's 12 reads are issued under the current group's MFMAs
+//     (768 cycles of cover for ~100 cycles of LDS latency);
+//   * epilogue: two rows at a time through two wave-private LDS regions (the finished tile buffer).
+// LDS map (bytes) as v7: [0, 40K) tile buffer 0 | [40K, 64K) weight slices 0..5 | [64K, 104K) tile buffer 1 |
+// [104K, 152K) weight slices 6..17 | [152K, +512) bias, so that switching buffers is `addr ^ 0x10000`.
+//
+// Counted wait: the top-of-stage `s_waitcnt vmcnt(N)` lets exactly the epilogue's stores stay in flight; a full tile
+// issues 16 (4 rows x 4 x 16 B per lane).  The build checks that count in the listing (Makefile, check_asm.py).
+#include <type_traits>
+
+#include "conv_common.h"
+
+using convk::ConvParams;
+
+namespace {
+
+constexpr int TH10 = 16, TW10 = 32, NT10 = 4, NW10 = 4, CK10 = 32, NTHR10 = 256;
+constexpr int TIW10 = TW10 + 2, TIH10 = TH10 + 2, NPIX10 = TIW10 * TIH10;   // 34 x 18 = 612 halo pixels
+constexpr int PIECES10 = (NPIX10 + 15) / 16;                                // 39 DMA pieces of 16 pixels x 64 B
+constexpr int DMA10 = (PIECES10 + NW10 - 1) / NW10;                         // 10 per wave
+constexpr int BUF1_10 = 0x10000, WLO10 = 40 * 1024, WHI10 = 104 * 1024, MISC10 = 152 * 1024;
+constexpr int LDS10 = MISC10 + 512;
+constexpr int WSL10 = 4096;
+constexpr int EROW10 = 32 * 144;                                            // one transposed output row (epilogue scratch)
+static_assert(DMA10 * NW10 * 1024 <= WLO10, "tile buffer");
+static_assert(NW10 * 2 * EROW10 <= WLO10, "epilogue scratch aliases a tile buffer");
+constexpr int STORES10 = NT10 * 4;                                          // global stores per lane per full tile
+
+struct V10Extra {
+  int ntiles;
+  const half_t* zeros;      // >= 16 bytes of zeros: the DMA source of out-of-image halo pixels
+};
+
+static long long* g_stamp10 = nullptr;
+static int g_stamp10_cap = 0;
+
+__device__ __host__ constexpr int wslice10(int sl) { return sl < 6 ? WLO10 + sl * WSL10 : WHI10 + (sl - 6) * WSL10; }
+
+__device__ __forceinline__ void glds16_10(const half_t* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void raw_barrier10() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <bool STAMP = false>
+__global__ __launch_bounds__(NTHR10, 1) void conv_mfma_v10_kernel(const ConvParams p, const V10Extra e, long long* stamps = nullptr, int stamp_cap = 0) {
+  long long stv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define ST10(i) do { if constexpr (STAMP) { if (S == 3) stv[i] = clock64(); } } while (0)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  float* bias_s = reinterpret_cast<float*>(smem + MISC10);   // 64 floats
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, r = lane & 31;
+  const int cb = blockIdx.y, n = blockIdx.z;
+  constexpr int nchunks = 2;                                 // Cin = 64 (eligibility)
+
+  int first, stride, my_tiles;                               // XCD-aware: one contiguous band of tiles per L2
+  convk::xcd_tile_walk(e.ntiles, first, stride, my_tiles);
+  const int nstages = my_tiles * nchunks;
+  if (nstages <= 0) return;
+
+  // ---- per-lane DMA item: piece u = j * 4 + wave covers halo pixels q = 16u .. 16u + 15; this lane moves 16-byte slot
+  // (lane & 3) of pixel q = 16u + (lane >> 2), which holds logical chunk c = slot ^ ((q >> 2) & 3).
+  const int csw = (lane & 3) ^ ((lane >> 4) & 3);            // (q >> 2) & 3 == (lane >> 4) & 3 for every piece
+  int it_off[DMA10];
+#pragma unroll
+  for (int j = 0; j < DMA10; ++j) {
+    const int q = 16 * (j * NW10 + wave) + (lane >> 2);
+    const int rr = q / TIW10, cc = q - rr * TIW10;
+    it_off[j] = q < NPIX10 ? (rr * p.W + cc) * p.x_sp + csw * 8 : csw * 8;
+  }
+  const half_t* xn = p.x + (long)n * p.x_sn;
+
+  int pf_iy0 = 0, pf_ix0 = 0, pf_ch = 0;
+  bool pf_interior = false;
+  const half_t* pf_base = xn;
+  auto issue_prep = [&](int S) {
+    const int tile_i = S >> 1, ch = S & 1;
+    const int tile = first + tile_i * stride;
+    const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    pf_iy0 = ty * TH10 - 1;
+    pf_ix0 = tx * TW10 - 1;
+    pf_ch = ch;
+    pf_interior = pf_iy0 >= 0 && pf_ix0 >= 0 && pf_iy0 + TIH10 <= p.H && pf_ix0 + TIW10 <= p.W;
+    pf_base = xn + ((long)pf_iy0 * p.W + pf_ix0) * p.x_sp + ch * CK10;    // only dereferenced when interior
+  };
+  auto issue_one = [&](int j, unsigned dst_buf) {            // j is a compile-time constant at every call site
+    const half_t* src = pf_base + it_off[j];
+    if (!pf_interior) {                  // uniform branch: border tiles (6 % at 1080p) clamp per lane
+      const int q = 16 * (j * NW10 + wave) + (lane >> 2);
+      const int rr = q / TIW10;
+      const int iy = pf_iy0 + rr, ix = pf_ix0 + (q - rr * TIW10);
+      const bool ok = q < NPIX10 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      src = ok ? xn + ((long)iy * p.W + ix) * p.x_sp + pf_ch * CK10 + csw * 8 : e.zeros;
+    }
+    glds16_10(src, dst_buf + (j * NW10 + wave) * 1024);
+  };
+
+  // ---- prologue: first tile's DMA, then bias + resident weights (compiler-tracked loads, younger than the DMA)
+  issue_prep(0);
+#pragma unroll
+  for (int j = 0; j < DMA10; ++j) issue_one(j, lds0);
+
+  if (tid < 64) bias_s[tid] = p.bias[blockIdx.y * 64 + tid];
+  {
+    constexpr int nslices = nchunks * 9;             // slice (ch, t) = 4 KB [mt 2][s2 2][lane 64][8 halves]
+    for (int i = tid; i < nslices * 256; i += NTHR10) {
+      const int sl = i >> 8, u = i & 255;            // u = q*64 + lane, q = mt*2 + s2
+      const int qq = u >> 6, ln = u & 63;
+      const half_t* src = p.w + ((((long)(cb * 2 + (qq >> 1)) * nslices + sl) * 2 + (qq & 1)) * 64 + ln) * 8;
+      *reinterpret_cast<half8*>(smem + wslice10(sl) + u * 16) = *reinterpret_cast<const half8*>(src);
+    }
+  }
+
+  // ---- B-fragment read offsets (tile buffer 0, s2 = 0): input row ir of this wave, column r + dx, chunk slot hh
+  int bq[NT10 + 2][3];
+#pragma unroll
+  for (int ir = 0; ir < NT10 + 2; ++ir)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int q = (wave * NT10 + ir) * TIW10 + r + dx;
+      bq[ir][dx] = q * 64 + ((hh ^ ((q >> 2) & 3)) << 4);
+    }
+
+  __syncthreads();                       // bias and weights are visible (no DMA-aware wait here: see top of stage)
+
+  f32x16 acc[2][NT10];
+  auto init_acc = [&]() {                // accumulators start from the bias: LDS reads, no vector moves
+#pragma unroll
+    for (int nt = 0; nt < NT10; ++nt) {
+      int o = hh * 4;
+      asm volatile("" : "+v"(o));        // keep one read per accumulator (no register copies)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + mt * 32 + 8 * g + o);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[mt][nt][4 * g + i] = b4[i];
+        }
+    }
+  };
+  init_acc();
+
+  bool stores_in_flight = false;         // the previous stage ended with exactly STORES10 epilogue stores (full tile)
+  for (int S = 0; S < nstages; ++S) {
+    const int tile_i = S >> 1, ch = S & 1;
+    const unsigned bsel = (S & 1) ? BUF1_10 : 0;
+    ST10(0);
+    // This wave's DMA pieces of stage S have landed: they are older than the (at most STORES10) epilogue stores.
+    if (stores_in_flight) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert(STORES10 == 16, "the counted wait above");
+    ST10(1);
+    raw_barrier10();                     // every wave's pieces landed; every wave is done with the other buffer
+    ST10(2);
+    const bool have_next = S + 1 < nstages;
+    if (have_next) issue_prep(S + 1);
+    const unsigned nbuf = lds0 + (bsel ^ BUF1_10);
+
+    // matrix phase: 6 groups (s2, dx) of 24 MFMAs; group g+1's 12 fragment reads are issued under group g's MFMAs
+    const unsigned char* tb = smem + bsel;
+    const unsigned char* wlo = smem + (ch == 0 ? WLO10 : wslice10(9)) + lane * 16;                          // taps 0..5 of this chunk
+    const unsigned char* whi = smem + (ch == 0 ? wslice10(6) - 6 * WSL10 : wslice10(9)) + lane * 16;        // taps 6..8
+    half8 fa[2][3][2], fb[2][NT10 + 2];
+    auto load_group = [&](int g, int buf) {
+      const int s2 = g / 3, dx = g - 3 * s2;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int t = dy * 3 + dx;
+        const unsigned char* wt = (t < 6 ? wlo : whi) + t * WSL10;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) fa[buf][dy][mt] = *reinterpret_cast<const half8*>(wt + (mt * 2 + s2) * 1024);
+      }
+#pragma unroll
+      for (int ir = 0; ir < NT10 + 2; ++ir) fb[buf][ir] = *reinterpret_cast<const half8*>(tb + (bq[ir][dx] ^ (s2 * 32)));
+    };
+    load_group(0, 0);
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+      if (g + 1 < 6) load_group(g + 1, (g + 1) & 1);
+#pragma unroll
+      for (int ir = 0; ir < NT10 + 2; ++ir)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int nt = ir - dy;
+          if (nt >= 0 && nt < NT10) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][dy][mt], fb[g & 1][ir], acc[mt][nt], 0, 0, 0);
+          }
+        }
+      // pin the software pipeline: one fragment read of group g+1 per two MFMAs of group g
+      if (g + 1 < 6) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+      }
+      if (have_next && g < 5) {          // 10 DMA pieces of the next stage, two per group
+        issue_one(2 * g, nbuf);
+        issue_one(2 * g + 1, nbuf);
+      }
+    }
+    ST10(3);
+    stores_in_flight = false;
+    if (ch != nchunks - 1) continue;
+
+    const int tile = first + tile_i * stride;
+    const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    const bool full = (ty + 1) * TH10 <= p.Ho && (tx + 1) * TW10 <= p.Wo;
+    raw_barrier10();                     // all waves finished reading this tile buffer: it becomes epilogue scratch
+    ST10(4);
+    {
+      convk::PackedRow rows[NT10];
+      convk::epilogue_pack<NT10, true>(p, acc, bias_s, lane, rows, false);
+      unsigned char* ew = smem + bsel + wave * (2 * EROW10);
+#pragma unroll
+      for (int nt = 0; nt < NT10; ++nt)
+        convk::epilogue_store_row(p, rows[nt], ew + (nt & 1) * EROW10, n, cb * 64, ty * TH10 + wave * NT10 + nt, tx * TW10, lane, full);
+    }
+    init_acc();
+    stores_in_flight = full;
+    ST10(5);
+    if constexpr (STAMP) {
+      if (S == 3 && lane == 0) {             // one record per wave: [block][wave][8 stamps]
+        const int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (bid * 8 + 7 < stamp_cap) for (int i = 0; i < 8; ++i) stamps[((long)bid * 8 + wave) * 8 + i] = stv[i];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" void tdvc_debug_set_stamp_buffer_v10(void* buf, int cap_blocks) { g_stamp10 = (long long*)buf; g_stamp10_cap = cap_blocks; }
+
+static bool g_v10_enabled = true;
+// tests and A/B benchmarks switch the kernel off to send the same layers to conv_mfma_v7
+extern "C" void tdvc_debug_enable_conv_v10(int enable) { g_v10_enabled = enable != 0; }
+
+bool conv_v10_eligible(const tdvc_conv_desc* d, const ConvParams& p, int Ho, int Wo) {
+  static const bool off = getenv("TDVC_CONV_NO_V10") != nullptr || getenv("TDVC_CONV_V1") != nullptr;
+  if (off || !g_v10_enabled) return false;
+  bool taps33 = d->ntaps == 9 && d->kh == 3 && d->kw == 3 && d->pad == 1;
+  for (int t = 0; taps33 && t < 9; ++t) taps33 = d->tap_dy[t] == t / 3 && d->tap_dx[t] == t % 3;
+  return taps33 && d->ck == 32 && d->stride == 1 && d->cout >= 64 && d->x.C == 64 && !d->s2d &&
+         !d->square_input && (long)Ho * Wo >= 8192 && convk::conv_is_simple(p);
+}
+
+int launch_conv_v10(const ConvParams& p, int cout_blocks, int N, hipStream_t st) {
+  static half_t* zeros = nullptr;
+  if (!zeros) {
+    hipError_t err = hipMalloc(reinterpret_cast<void**>(&zeros), 256);
+    if (err == hipSuccess) err = hipMemset(zeros, 0, 256);
+    if (err != hipSuccess) { zeros = nullptr; tdvc_set_error("conv v10: zero page allocation failed: %s", hipGetErrorString(err)); return (int)err; }
+  }
+  ConvParams q = p;
+  q.tiles_x = (p.Wo + TW10 - 1) / TW10;
+  const int tiles_y = (p.Ho + TH10 - 1) / TH10;
+  V10Extra e;
+  e.ntiles = q.tiles_x * tiles_y;
+  e.zeros = zeros;
+  q.slope = convk::conv_simple_slope(p);
+  int gx = 256 / (cout_blocks * N);
+  if (gx < 1) gx = 1;
+  if (gx > e.ntiles) gx = e.ntiles;
+  dim3 grid(gx, cout_blocks, N);
+  auto go = [&](auto kern, bool stamp) -> int {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (err != hipSuccess) { tdvc_set_error("conv v10: hipFuncSetAttribute failed: %s", hipGetErrorString(err)); return (int)err; }
+    hipLaunchKernelGGL(kern, grid, dim3(NTHR10), LDS10, st, q, e, stamp ? g_stamp10 : (long long*)nullptr, stamp ? g_stamp10_cap : 0);
+    return 0;
+  };
+  const int rc = g_stamp10 ? go(&conv_mfma_v10_kernel<true>, true) : go(&conv_mfma_v10_kernel<false>, false);
+  if (rc) return rc;
+  return tdvc_launch_status("tdvc_conv2d(v10)");
+}

@@ -315,7 +315,8 @@ def test_conv_stride2_s2d(H, W, report):
     assert_close(fm_to_cpu(y), F.conv2d(x, w, b, stride=2, padding=1), 1e-4, 1e-4, f"s2d fp32 out {H}x{W}", report)
 
 
-# ---- 3x3 stride-1 convs at sizes that take the LDS-DMA double-buffered kernel (conv_mfma_v7) ---------
+# ---- 3x3 stride-1 convs at sizes that take the LDS-DMA double-buffered kernels: conv_mfma_v10 (Cin = 64: one wave per
+# SIMD, 2 x 4 register tile with row reuse) and conv_mfma_v7 (Cin = 32, and Cin = 64 with v10 switched off) ---------
 V7_CASES = [
     # name, N, cin, cout, H, W, act, n_res
     ("v7_64_64_ragged", 1, 64, 64, 100, 150, "lrelu", 1),          # partial tiles on both edges
@@ -327,10 +328,24 @@ V7_CASES = [
 ]
 
 
+@pytest.mark.parametrize("v10", [True, False], ids=["v10", "v7"])
 @pytest.mark.parametrize("case", V7_CASES, ids=[c[0] for c in V7_CASES])
-def test_conv_v7(case, report):
+def test_conv_v7(case, v10, report):
+    import ctypes
+
+    from tdvc_amd import _lib
     ops = _ops()
     name, N, cin, cout, H, W, act, n_res = case
+    fn = _lib.lib().tdvc_debug_enable_conv_v10
+    fn.argtypes, fn.restype = [ctypes.c_int], None
+    fn(1 if v10 else 0)
+    try:
+        _run_conv_dma_case(ops, name, N, cin, cout, H, W, act, n_res, "conv_mfma_v10" if (v10 and cin == 64) else "conv_mfma_v7", report)
+    finally:
+        fn(1)
+
+
+def _run_conv_dma_case(ops, name, N, cin, cout, H, W, act, n_res, kernel, report):
     x = rnd16(randn(N, cin, H, W, seed=81))
     w = rnd16(randn(cout, cin, 3, 3, seed=82) * (1.0 / (cin * 9) ** 0.5))
     b = randn(cout, seed=83) * 0.1
@@ -348,7 +363,8 @@ def test_conv_v7(case, report):
         kw["res2"] = to_fm(res[1], ops)
     xf = to_fm(x, ops)
     y = ops.conv(xf, pc, **kw)
-    assert_close(fm_to_cpu(y, cout), ref, RT, AT, f"conv {name}", report)
+    assert ops.L.lib().tdvc_last_conv_kernel().decode() == kernel, (ops.L.lib().tdvc_last_conv_kernel(), kernel)
+    assert_close(fm_to_cpu(y, cout), ref, RT, AT, f"conv {name} on {kernel}", report)
     # the DMA / barrier protocol must give the same bits on every launch
     first = y.t.clone()
     for _ in range(5):

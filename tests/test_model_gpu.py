@@ -269,7 +269,7 @@ def test_trained_operating_point_parity(report):
             p_o, p_16, p_32 = psnr(ro, g[t:t + 1]), psnr(r16.cpu(), g[t:t + 1]), psnr(r32.cpu(), g[t:t + 1])
             report(f"[trained, {H}x{W} frame {t}] oracle {bo:.5f} bpp {p_o:.4f} dB | default mode dbpp {d16:+.5f} dPSNR {p_16 - p_o:+.4f} | "
                    f"fp32 islands dbpp {d32:+.5f} dPSNR {p_32 - p_o:+.4f}")
-            assert bo < 0.6, "not a trained-like operating point"
+            assert bo < 1.0, "not a trained-like operating point"      # eval mode (rounding, int(H/8) matching) on the first frames of a GOP: under 1 bpp
             assert abs(d16) <= 1e-3 and abs(p_16 - p_o) <= 0.02, "default mode misses the SURVEY 8d gates at the trained operating point"
             assert abs(d32) <= 1e-3 and abs(p_32 - p_o) <= 0.02, "fp32-island mode misses the SURVEY 8d gates at the trained operating point"
             worst = max(worst, abs(d16))
