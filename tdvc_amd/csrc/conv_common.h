@@ -279,4 +279,97 @@ __device__ __forceinline__ void epilogue_simple_rows(const ConvParams& p, f32x16
   for (int nt = 0; nt < NTX; ++nt) epilogue_store_row(p, rows[nt], ew, n, cbase, oy_first + nt, ox_first, lane, full);
 }
 
+// Lean epilogue of the weight-stationary 3x3 kernel (conv_mfma_v10): what `conv_is_lean` admits -- fp16 NHWC output,
+// no GDN, no PixelShuffle, bias already in the accumulators, activation max(v, v * slope), NRES fp16 residuals known at
+// compile time.  The generic transposed epilogue above carries every mode as run-time branches (1.4 k vector instructions
+// per 16x32 tile per wave, 0.9 k s_nop of hazard padding between its fp32 conversions); with one wave per SIMD those
+// instructions are serial time in which the matrix pipe idles.  Here a 2-row round is: residual loads first (their
+// latency runs under the packing), 64 accumulators -> packed fp16 (v_cvt_pk_f16_f32), activation as packed fp16 math
+// (what the reference's autocast computes: the conv result is an fp16 tensor, LeakyReLU runs on it), 16 ds_write_b64 into
+// two wave-private 32 x 144 B regions, 8 ds_read_b128, packed fp16 residual adds, 8 full-line stores.
+inline bool conv_is_lean(const ConvParams& p) {
+  return conv_is_simple(p) && p.out_mode == TDVC_OUT_NHWC && !p.gdn;
+}
+
+template <int NRES, int NR, bool STAMPED = false>
+__device__ __forceinline__ void epilogue_lean_rows(const ConvParams& p, const f32x16 (&acc)[2][NR], unsigned char* ew, int n,
+                                                   int cbase, int oy, int ox_first, int lane, bool full, long long* st = nullptr) {
+#define EST(i) do { if constexpr (STAMPED) { if (st) st[i] = clock64(); } } while (0)
+  static_assert(NR % 2 == 0, "two rows per round");
+  constexpr int EPS = 144, EROW = 32 * EPS;
+  const int hh = lane >> 5, r = lane & 31;
+  const int chunk = lane & 7, prow = lane >> 3;
+  const int co = cbase + chunk * 8;
+  const bool ch_ok = co < p.y.C && co < ((p.cout + 63) & ~63);
+  const int cc = ch_ok ? co : 0;
+  int opix[NR][4];
+  bool ok[NR][4];
+#pragma unroll
+  for (int j = 0; j < NR; ++j)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ox = ox_first + k * 8 + prow;
+      ok[j][k] = full ? ch_ok : (ch_ok && oy + j < p.Ho && ox < p.Wo);
+      opix[j][k] = ok[j][k] ? (oy + j) * p.Wo + ox : 0;
+    }
+  // every residual load of the tile goes out before the first store: the compiler's waits on them are then counted
+  // (vmcnt(k), k = younger stores) instead of draining the previous round's stores
+  half8 r1[NR][4], r2[NR][4];
+  if constexpr (NRES >= 1) {
+    const half_t* rb = reinterpret_cast<const half_t*>(p.res.p) + (long)n * p.res.sn + cc;
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r1[j][k] = *reinterpret_cast<const half8*>(rb + (long)opix[j][k] * p.res.sp);
+  }
+  if constexpr (NRES >= 2) {
+    const half_t* rb = reinterpret_cast<const half_t*>(p.res2.p) + (long)n * p.res2.sn + cc;
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r2[j][k] = *reinterpret_cast<const half8*>(rb + (long)opix[j][k] * p.res2.sp);
+  }
+  const half_t sl = (half_t)p.slope;
+  const half2v sl2 = {sl, sl};
+  const bool act = p.slope != 1.f;                       // wave-uniform: no activation -> no packed math at all
+  half_t* yb = reinterpret_cast<half_t*>(p.y.p) + (long)n * p.y.sn + cc;
+  EST(0);
+#pragma unroll
+  for (int j0 = 0; j0 < NR; j0 += 2) {
+#pragma unroll
+    for (int j = j0; j < j0 + 2; ++j)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          half2v lo = {(half_t)acc[mt][j][4 * g + 0], (half_t)acc[mt][j][4 * g + 1]};
+          half2v hi = {(half_t)acc[mt][j][4 * g + 2], (half_t)acc[mt][j][4 * g + 3]};
+          if (act) {
+            lo = __builtin_elementwise_max(lo, lo * sl2);
+            hi = __builtin_elementwise_max(hi, hi * sl2);
+          }
+          half4 o = {lo[0], lo[1], hi[0], hi[1]};
+          *reinterpret_cast<half4*>(ew + (j & 1) * EROW + r * EPS + (mt * 32 + 8 * g + 4 * hh) * 2) = o;
+        }
+    EST(1 + 3 * (j0 / 2));                 // packed + written to LDS (issue)
+    half8 h[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) h[j][k] = *reinterpret_cast<const half8*>(ew + j * EROW + (k * 8 + prow) * EPS + chunk * 16);
+    EST(2 + 3 * (j0 / 2));                 // transposed values back (clock64 drains lgkmcnt)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        half8 v = h[j][k];
+        if constexpr (NRES >= 1) v = v + r1[j0 + j][k];
+        if constexpr (NRES >= 2) v = v + r2[j0 + j][k];
+        if (ok[j0 + j][k]) *reinterpret_cast<half8*>(yb + (long)opix[j0 + j][k] * p.y.sp) = v;
+      }
+    EST(3 + 3 * (j0 / 2));                 // stores issued
+  }
+#undef EST
+}
+
 }  // namespace convk

@@ -19,8 +19,9 @@
 // LDS map (bytes) as v7: [0, 40K) tile buffer 0 | [40K, 64K) weight slices 0..5 | [64K, 104K) tile buffer 1 |
 // [104K, 152K) weight slices 6..17 | [152K, +512) bias, so that switching buffers is `addr ^ 0x10000`.
 //
-// Counted wait: the top-of-stage `s_waitcnt vmcnt(N)` lets exactly the epilogue's stores stay in flight; a full tile
-// issues 16 (4 rows x 4 x 16 B per lane).  The build checks that count in the listing (Makefile, check_asm.py).
+//   * memory traffic kept off the critical path: residual rows are fetched at the start of a tile's second stage, the
+//     epilogue only packs / transposes / adds, and the tile's 16 stores go out under the next tile's first stage; every
+//     vector-memory wait is a plain vmcnt(0) at a stage top (no hand-counted wait: see "epilogue state" in the kernel).
 #include <type_traits>
 
 #include "conv_common.h"
@@ -39,7 +40,6 @@ constexpr int WSL10 = 4096;
 constexpr int EROW10 = 32 * 144;                                            // one transposed output row (epilogue scratch)
 static_assert(DMA10 * NW10 * 1024 <= WLO10, "tile buffer");
 static_assert(NW10 * 2 * EROW10 <= WLO10, "epilogue scratch aliases a tile buffer");
-constexpr int STORES10 = NT10 * 4;                                          // global stores per lane per full tile
 
 struct V10Extra {
   int ntiles;
@@ -62,10 +62,11 @@ __device__ __forceinline__ void raw_barrier10() {
   asm volatile("" ::: "memory");
 }
 
-template <bool STAMP = false>
+template <int NRES, bool STAMP = false>
 __global__ __launch_bounds__(NTHR10, 1) void conv_mfma_v10_kernel(const ConvParams p, const V10Extra e, long long* stamps = nullptr, int stamp_cap = 0) {
-  long long stv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define ST10(i) do { if constexpr (STAMP) { if (S == 3) stv[i] = clock64(); } } while (0)
+  long long stv[24];
+  if constexpr (STAMP) { for (int i = 0; i < 24; ++i) stv[i] = 0; }
+#define ST10(i) do { if constexpr (STAMP) { if (ti == 1 && ch == 1) stv[i] = clock64(); } } while (0)
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   float* bias_s = reinterpret_cast<float*>(smem + MISC10);   // 64 floats
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
@@ -78,8 +79,7 @@ __global__ __launch_bounds__(NTHR10, 1) void conv_mfma_v10_kernel(const ConvPara
 
   int first, stride, my_tiles;                               // XCD-aware: one contiguous band of tiles per L2
   convk::xcd_tile_walk(e.ntiles, first, stride, my_tiles);
-  const int nstages = my_tiles * nchunks;
-  if (nstages <= 0) return;
+  if (my_tiles <= 0) return;
 
   // ---- per-lane DMA item: piece u = j * 4 + wave covers halo pixels q = 16u .. 16u + 15; this lane moves 16-byte slot
   // (lane & 3) of pixel q = 16u + (lane >> 2), which holds logical chunk c = slot ^ ((q >> 2) & 3).
@@ -93,13 +93,11 @@ __global__ __launch_bounds__(NTHR10, 1) void conv_mfma_v10_kernel(const ConvPara
   }
   const half_t* xn = p.x + (long)n * p.x_sn;
 
+  // ---- the tile whose DMA is being issued: (pf_ty, pf_tx) advance by `stride` tiles without a division
   int pf_iy0 = 0, pf_ix0 = 0, pf_ch = 0;
   bool pf_interior = false;
   const half_t* pf_base = xn;
-  auto issue_prep = [&](int S) {
-    const int tile_i = S >> 1, ch = S & 1;
-    const int tile = first + tile_i * stride;
-    const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+  auto issue_prep = [&](int ty, int tx, int ch) {
     pf_iy0 = ty * TH10 - 1;
     pf_ix0 = tx * TW10 - 1;
     pf_ch = ch;
@@ -119,7 +117,8 @@ __global__ __launch_bounds__(NTHR10, 1) void conv_mfma_v10_kernel(const ConvPara
   };
 
   // ---- prologue: first tile's DMA, then bias + resident weights (compiler-tracked loads, younger than the DMA)
-  issue_prep(0);
+  int ty = first / p.tiles_x, tx = first - ty * p.tiles_x;   // the tile being computed
+  issue_prep(ty, tx, 0);
 #pragma unroll
   for (int j = 0; j < DMA10; ++j) issue_one(j, lds0);
 
@@ -164,94 +163,189 @@ __global__ __launch_bounds__(NTHR10, 1) void conv_mfma_v10_kernel(const ConvPara
   };
   init_acc();
 
-  bool stores_in_flight = false;         // the previous stage ended with exactly STORES10 epilogue stores (full tile)
-  for (int S = 0; S < nstages; ++S) {
-    const int tile_i = S >> 1, ch = S & 1;
-    const unsigned bsel = (S & 1) ? BUF1_10 : 0;
-    ST10(0);
-    // This wave's DMA pieces of stage S have landed: they are older than the (at most STORES10) epilogue stores.
-    if (stores_in_flight) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    static_assert(STORES10 == 16, "the counted wait above");
-    ST10(1);
-    raw_barrier10();                     // every wave's pieces landed; every wave is done with the other buffer
-    ST10(2);
-    const bool have_next = S + 1 < nstages;
-    if (have_next) issue_prep(S + 1);
-    const unsigned nbuf = lds0 + (bsel ^ BUF1_10);
+  // ---- epilogue state.  Every CU moves ~10 B per cycle to / from HBM: a tile's 64 KB of residual reads and 64 KB of
+  // stores issued as one burst after the matrix phase cost 6-7 k cycles each in which no MFMA runs (stamps).
+  // So the residuals of tile i are fetched into registers at the START of its second stage (4.6 k cycles of cover), the
+  // epilogue only packs / transposes / adds into `pend`, and the 16 stores of tile i go out four per matrix group under
+  // the FIRST stage of tile i+1.  All vector-memory waits are then vmcnt(0) at a stage top, where the youngest
+  // operations are DMA pieces issued >= one group (768 cycles) after the last store: no hand-counted wait is left.
+  const int chunk = lane & 7, prow = lane >> 3;
+  const int co = cb * 64 + chunk * 8;
+  const bool ch_ok = co < p.y.C && co < ((p.cout + 63) & ~63);
+  const int ccl = ch_ok ? co : 0;
+  half8 pend[NT10][4];                   // finished output rows of the previous tile (this lane's 8 channels of 4 pixels per row)
+  int pend_opix[NT10][4];
+  unsigned pend_mask = 0;                // bit (j * 4 + k): store (row j, pixel group k); 0 = nothing pending
+  half8 r1[NT10][4], r2[NT10][4];
+  int cur_opix[NT10][4];
+  unsigned cur_mask = 0;
+  half_t* yb = reinterpret_cast<half_t*>(p.y.p) + (long)n * p.y.sn + ccl;
+  auto store_pending = [&](int j) {      // row j of the pending tile: 4 full-line stores
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (pend_mask & (1u << (j * 4 + k))) *reinterpret_cast<half8*>(yb + (long)pend_opix[j][k] * p.y.sp) = pend[j][k];
+  };
 
-    // matrix phase: 6 groups (s2, dx) of 24 MFMAs; group g+1's 12 fragment reads are issued under group g's MFMAs
-    const unsigned char* tb = smem + bsel;
-    const unsigned char* wlo = smem + (ch == 0 ? WLO10 : wslice10(9)) + lane * 16;                          // taps 0..5 of this chunk
-    const unsigned char* whi = smem + (ch == 0 ? wslice10(6) - 6 * WSL10 : wslice10(9)) + lane * 16;        // taps 6..8
-    half8 fa[2][3][2], fb[2][NT10 + 2];
-    auto load_group = [&](int g, int buf) {
-      const int s2 = g / 3, dx = g - 3 * s2;
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    const bool last_tile = ti + 1 == my_tiles;
+    int nty = ty, ntx = tx + stride;     // the next tile of this workgroup
+    while (ntx >= p.tiles_x) { ntx -= p.tiles_x; ++nty; }
+
+    auto stage = [&](auto CH) {
+      constexpr int ch = decltype(CH)::value;
+      constexpr unsigned bsel = ch ? BUF1_10 : 0;
+      ST10(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's DMA pieces of the stage (and every older store / load) are done
+      ST10(1);
+      raw_barrier10();                   // every wave's pieces landed; every wave is done with the other buffer
+      ST10(2);
+      const bool have_next = ch == 0 || !last_tile;
+      if (ch == 0) issue_prep(ty, tx, 1);
+      else if (have_next) issue_prep(nty, ntx, 0);
+      const unsigned nbuf = lds0 + (bsel ^ BUF1_10);
+      if constexpr (ch == 1) {           // this tile's output geometry + residual prefetch (consumed by the epilogue below)
+        const int oy = ty * TH10 + wave * NT10, ox_first = tx * TW10;
+        const bool full = (ty + 1) * TH10 <= p.Ho && (tx + 1) * TW10 <= p.Wo;
+        cur_mask = 0;
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const int t = dy * 3 + dx;
-        const unsigned char* wt = (t < 6 ? wlo : whi) + t * WSL10;
+        for (int j = 0; j < NT10; ++j)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) fa[buf][dy][mt] = *reinterpret_cast<const half8*>(wt + (mt * 2 + s2) * 1024);
+          for (int k = 0; k < 4; ++k) {
+            const int ox = ox_first + k * 8 + prow;
+            const bool ok = full ? ch_ok : (ch_ok && oy + j < p.Ho && ox < p.Wo);
+            cur_opix[j][k] = ok ? (oy + j) * p.Wo + ox : 0;
+            cur_mask |= ok ? (1u << (j * 4 + k)) : 0u;
+          }
+        if constexpr (NRES >= 1) {
+          const half_t* rb = reinterpret_cast<const half_t*>(p.res.p) + (long)n * p.res.sn + ccl;
+#pragma unroll
+          for (int j = 0; j < NT10; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r1[j][k] = *reinterpret_cast<const half8*>(rb + (long)cur_opix[j][k] * p.res.sp);
+        }
+        if constexpr (NRES >= 2) {
+          const half_t* rb = reinterpret_cast<const half_t*>(p.res2.p) + (long)n * p.res2.sn + ccl;
+#pragma unroll
+          for (int j = 0; j < NT10; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r2[j][k] = *reinterpret_cast<const half8*>(rb + (long)cur_opix[j][k] * p.res2.sp);
+        }
       }
-#pragma unroll
-      for (int ir = 0; ir < NT10 + 2; ++ir) fb[buf][ir] = *reinterpret_cast<const half8*>(tb + (bq[ir][dx] ^ (s2 * 32)));
-    };
-    load_group(0, 0);
-#pragma unroll
-    for (int g = 0; g < 6; ++g) {
-      if (g + 1 < 6) load_group(g + 1, (g + 1) & 1);
-#pragma unroll
-      for (int ir = 0; ir < NT10 + 2; ++ir)
+
+      // matrix phase: 6 groups (s2, dx) of 24 MFMAs; group g+1's 12 fragment reads are issued under group g's MFMAs
+      const unsigned char* tb = smem + bsel;
+      const unsigned char* wlo = smem + (ch == 0 ? WLO10 : wslice10(9)) + lane * 16;                          // taps 0..5 of this chunk
+      const unsigned char* whi = smem + (ch == 0 ? wslice10(6) - 6 * WSL10 : wslice10(9)) + lane * 16;        // taps 6..8
+      half8 fa[2][3][2], fb[2][NT10 + 2];
+      auto load_group = [&](int g, int buf) {
+        const int s2 = g / 3, dx = g - 3 * s2;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
-          const int nt = ir - dy;
-          if (nt >= 0 && nt < NT10) {
+          const int t = dy * 3 + dx;
+          const unsigned char* wt = (t < 6 ? wlo : whi) + t * WSL10;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][dy][mt], fb[g & 1][ir], acc[mt][nt], 0, 0, 0);
+          for (int mt = 0; mt < 2; ++mt) fa[buf][dy][mt] = *reinterpret_cast<const half8*>(wt + (mt * 2 + s2) * 1024);
+        }
+#pragma unroll
+        for (int ir = 0; ir < NT10 + 2; ++ir) fb[buf][ir] = *reinterpret_cast<const half8*>(tb + (bq[ir][dx] ^ (s2 * 32)));
+      };
+      load_group(0, 0);
+      __builtin_amdgcn_sched_barrier(0);   // group 0's own 12 reads go out back to back (one latency), not read-by-read
+                                           // between its MFMAs: the interleave pattern below is for the NEXT group's reads
+#pragma unroll
+      for (int g = 0; g < 6; ++g) {
+        if (g + 1 < 6) load_group(g + 1, (g + 1) & 1);
+#pragma unroll
+        for (int ir = 0; ir < NT10 + 2; ++ir)
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            const int nt = ir - dy;
+            if (nt >= 0 && nt < NT10) {
+#pragma unroll
+              for (int mt = 0; mt < 2; ++mt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][dy][mt], fb[g & 1][ir], acc[mt][nt], 0, 0, 0);
+            }
+          }
+        // pin the software pipeline: one fragment read of group g+1 per two MFMAs of group g
+        if (g + 1 < 6) {
+#pragma unroll
+          for (int k = 0; k < 12; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
           }
         }
-      // pin the software pipeline: one fragment read of group g+1 per two MFMAs of group g
-      if (g + 1 < 6) {
+        if constexpr (ch == 0) {           // the previous tile's output: one row (4 stores) per group, all older than
+          if (g < NT10 && pend_mask) store_pending(g);     // the group-4 DMA pieces the next stage top waits for
+        }
+        if (have_next && g < 5) {          // 10 DMA pieces of the next stage, two per group
+          issue_one(2 * g, nbuf);
+          issue_one(2 * g + 1, nbuf);
+        }
+        ST10(8 + g);
+      }
+      ST10(3);
+    };
+    stage(std::integral_constant<int, 0>{});
+    stage(std::integral_constant<int, 1>{});
+
+    {
+      constexpr int ch = 1;
+      raw_barrier10();                     // all waves finished reading tile buffer 1: it becomes epilogue scratch
+      ST10(4);
+      // epilogue: pack (fp16, packed activation) -> wave-private LDS rows -> 8 channels x 4 pixels per lane -> + residuals -> pend
+      constexpr int EPS = 144;
+      unsigned char* ew = smem + BUF1_10 + wave * (2 * EROW10);
+      const half_t sl = (half_t)p.slope;
+      const half2v sl2 = {sl, sl};
+      const bool act = p.slope != 1.f;     // wave-uniform: no activation -> no packed math at all
+      const bool relu = p.slope == 0.f;    // ReLU: one packed max against zero (half of the 64-channel layers)
+      const half2v zero2 = {(half_t)0.f, (half_t)0.f};
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      for (int j0 = 0; j0 < NT10; j0 += 2) {
+#pragma unroll
+        for (int j = j0; j < j0 + 2; ++j)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              half2v lo = {(half_t)acc[mt][j][4 * g + 0], (half_t)acc[mt][j][4 * g + 1]};
+              half2v hi = {(half_t)acc[mt][j][4 * g + 2], (half_t)acc[mt][j][4 * g + 3]};
+              if (relu) {
+                lo = __builtin_elementwise_max(lo, zero2);
+                hi = __builtin_elementwise_max(hi, zero2);
+              } else if (act) {
+                lo = __builtin_elementwise_max(lo, lo * sl2);
+                hi = __builtin_elementwise_max(hi, hi * sl2);
+              }
+              half4 o = {lo[0], lo[1], hi[0], hi[1]};
+              *reinterpret_cast<half4*>(ew + (j & 1) * EROW10 + r * EPS + (mt * 32 + 8 * g + 4 * hh) * 2) = o;
+            }
+#pragma unroll
+        for (int j = j0; j < j0 + 2; ++j)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            half8 v = *reinterpret_cast<const half8*>(ew + (j & 1) * EROW10 + (k * 8 + prow) * EPS + chunk * 16);
+            if constexpr (NRES >= 1) v = v + r1[j][k];
+            if constexpr (NRES >= 2) v = v + r2[j][k];
+            pend[j][k] = v;
+            pend_opix[j][k] = cur_opix[j][k];
+          }
+      }
+      pend_mask = cur_mask;
+      init_acc();
+      ST10(5);
+      if constexpr (STAMP) {
+        if (ti == 1 && lane == 0) {          // one record per wave: [block][wave][24 stamps]
+          const int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+          if (bid * 4 + 3 < stamp_cap) for (int i = 0; i < 24; ++i) stamps[((long)bid * 4 + wave) * 24 + i] = stv[i];
         }
       }
-      if (have_next && g < 5) {          // 10 DMA pieces of the next stage, two per group
-        issue_one(2 * g, nbuf);
-        issue_one(2 * g + 1, nbuf);
-      }
     }
-    ST10(3);
-    stores_in_flight = false;
-    if (ch != nchunks - 1) continue;
-
-    const int tile = first + tile_i * stride;
-    const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-    const bool full = (ty + 1) * TH10 <= p.Ho && (tx + 1) * TW10 <= p.Wo;
-    raw_barrier10();                     // all waves finished reading this tile buffer: it becomes epilogue scratch
-    ST10(4);
-    {
-      convk::PackedRow rows[NT10];
-      convk::epilogue_pack<NT10, true>(p, acc, bias_s, lane, rows, false);
-      unsigned char* ew = smem + bsel + wave * (2 * EROW10);
-#pragma unroll
-      for (int nt = 0; nt < NT10; ++nt)
-        convk::epilogue_store_row(p, rows[nt], ew + (nt & 1) * EROW10, n, cb * 64, ty * TH10 + wave * NT10 + nt, tx * TW10, lane, full);
-    }
-    init_acc();
-    stores_in_flight = full;
-    ST10(5);
-    if constexpr (STAMP) {
-      if (S == 3 && lane == 0) {             // one record per wave: [block][wave][8 stamps]
-        const int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        if (bid * 8 + 7 < stamp_cap) for (int i = 0; i < 8; ++i) stamps[((long)bid * 8 + wave) * 8 + i] = stv[i];
-      }
-    }
+    ty = nty;
+    tx = ntx;
   }
+#pragma unroll
+  for (int j = 0; j < NT10; ++j) store_pending(j);           // the last tile's rows
 }
 
 }  // namespace
@@ -268,7 +362,7 @@ bool conv_v10_eligible(const tdvc_conv_desc* d, const ConvParams& p, int Ho, int
   bool taps33 = d->ntaps == 9 && d->kh == 3 && d->kw == 3 && d->pad == 1;
   for (int t = 0; taps33 && t < 9; ++t) taps33 = d->tap_dy[t] == t / 3 && d->tap_dx[t] == t % 3;
   return taps33 && d->ck == 32 && d->stride == 1 && d->cout >= 64 && d->x.C == 64 && !d->s2d &&
-         !d->square_input && (long)Ho * Wo >= 8192 && convk::conv_is_simple(p);
+         !d->square_input && (long)Ho * Wo >= 8192 && convk::conv_is_lean(p);
 }
 
 int launch_conv_v10(const ConvParams& p, int cout_blocks, int N, hipStream_t st) {
@@ -295,7 +389,11 @@ int launch_conv_v10(const ConvParams& p, int cout_blocks, int N, hipStream_t st)
     hipLaunchKernelGGL(kern, grid, dim3(NTHR10), LDS10, st, q, e, stamp ? g_stamp10 : (long long*)nullptr, stamp ? g_stamp10_cap : 0);
     return 0;
   };
-  const int rc = g_stamp10 ? go(&conv_mfma_v10_kernel<true>, true) : go(&conv_mfma_v10_kernel<false>, false);
+  const int nres = (p.res.p ? 1 : 0) + (p.res2.p ? 1 : 0);
+  if (nres == 1 && !p.res.p) { q.res = q.res2; q.res2 = null_fmap(); }        // a single residual is always `res`
+  int rc;
+  if (g_stamp10) rc = nres == 0 ? go(&conv_mfma_v10_kernel<0, true>, true) : nres == 1 ? go(&conv_mfma_v10_kernel<1, true>, true) : go(&conv_mfma_v10_kernel<2, true>, true);
+  else rc = nres == 0 ? go(&conv_mfma_v10_kernel<0, false>, false) : nres == 1 ? go(&conv_mfma_v10_kernel<1, false>, false) : go(&conv_mfma_v10_kernel<2, false>, false);
   if (rc) return rc;
   return tdvc_launch_status("tdvc_conv2d(v10)");
 }
