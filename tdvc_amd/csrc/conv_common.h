@@ -268,11 +268,108 @@ __device__ __forceinline__ void epilogue_store_row(const ConvParams& p, const Pa
   }
 }
 
-// immediate form used by conv_mfma (v1), v2 and v3
-template <int NTX, bool BIAS_IN_ACC = false>
+// Lean form of the transposed epilogue (host: conv_is_lean -> ConvParams::simple == 2): fp16 NHWC output, no GDN, no
+// PixelShuffle.  The generic form above carries every mode as run-time branches: ~700 vector instructions per two rows
+// plus ~450 s_nop of hazard padding between its fp32 conversions (listing of conv_mfma_v10 before the split), serial
+// time in which the wave issues no MFMA.  Here one row is: residual loads first (their latency runs under the packing),
+// 32 accumulators (+ bias) -> packed fp16 (v_cvt_pk_f16_f32), activation as packed fp16 math (what the reference's
+// autocast computes: the conv result is an fp16 tensor and ReLU / LeakyReLU runs on it), 8 ds_write_b64, 4
+// ds_read_b128, packed fp16 residual adds, 4 full-line stores: ~90 vector instructions.
+template <int NTX, bool BIAS_IN_ACC>
+__device__ __forceinline__ void epilogue_lean_seq(const ConvParams& p, f32x16 (&acc)[2][NTX], const float* bias64, unsigned char* ew, int n,
+                                                  int cbase, int oy_first, int ox_first, int lane, bool zero_acc, bool full) {
+  constexpr int EPS = 144;
+  const int hh = lane >> 5, r = lane & 31;
+  const int chunk = lane & 7, prow = lane >> 3;
+  const int co = cbase + chunk * 8;
+  const bool ch_ok = co < p.y.C && co < ((p.cout + 63) & ~63);
+  const int cc = ch_ok ? co : 0;
+  const bool has1 = p.res.p != nullptr, has2 = p.res2.p != nullptr;       // wave-uniform
+  const half_t sl = (half_t)p.slope;
+  const half2v sl2 = {sl, sl}, zero2 = {(half_t)0.f, (half_t)0.f};
+  const bool act = p.slope != 1.f, relu = p.slope == 0.f;                  // wave-uniform
+  half_t* yb = reinterpret_cast<half_t*>(p.y.p) + (long)n * p.y.sn + cc;
+  const half_t* rb1 = reinterpret_cast<const half_t*>(p.res.p) + (long)n * p.res.sn + cc;
+  const half_t* rb2 = reinterpret_cast<const half_t*>(p.res2.p) + (long)n * p.res2.sn + cc;
+  f32x4 b4[2][4];
+  if constexpr (!BIAS_IN_ACC) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) b4[mt][g] = *reinterpret_cast<const f32x4*>(bias64 + mt * 32 + 8 * g + 4 * hh);
+  }
+#pragma unroll
+  for (int nt = 0; nt < NTX; ++nt) {
+    const int oy = oy_first + nt;
+    int opix[4];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ox = ox_first + k * 8 + prow;
+      ok[k] = full ? ch_ok : (ch_ok && oy < p.Ho && ox < p.Wo);
+      opix[k] = ok[k] ? oy * p.Wo + ox : 0;
+    }
+    half8 r1[4], r2[4];
+    if (has1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r1[k] = *reinterpret_cast<const half8*>(rb1 + (long)opix[k] * p.res.sp);
+    }
+    if (has2) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r2[k] = *reinterpret_cast<const half8*>(rb2 + (long)opix[k] * p.res2.sp);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] = acc[mt][nt][4 * g + i];
+          if constexpr (!BIAS_IN_ACC) {
+            v[i] += b4[mt][g][i];
+            if (zero_acc) acc[mt][nt][4 * g + i] = 0.f;
+          }
+        }
+        half2v lo = {(half_t)v[0], (half_t)v[1]}, hi = {(half_t)v[2], (half_t)v[3]};
+        if (relu) {
+          lo = __builtin_elementwise_max(lo, zero2);
+          hi = __builtin_elementwise_max(hi, zero2);
+        } else if (act) {
+          lo = __builtin_elementwise_max(lo, lo * sl2);
+          hi = __builtin_elementwise_max(hi, hi * sl2);
+        }
+        const half4 o = {lo[0], lo[1], hi[0], hi[1]};
+        *reinterpret_cast<half4*>(ew + r * EPS + (mt * 32 + 8 * g + 4 * hh) * 2) = o;
+      }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      half8 v = *reinterpret_cast<const half8*>(ew + (k * 8 + prow) * EPS + chunk * 16);
+      if (has1) v = v + r1[k];
+      if (has2) v = v + r2[k];
+      if (ok[k]) *reinterpret_cast<half8*>(yb + (long)opix[k] * p.y.sp) = v;
+    }
+  }
+}
+
+// immediate form used by conv_mfma (v1), v2, v3, v5 and v7 (v7: generic only, its counted wait is checked against ONE
+// epilogue's store count)
+// MODE: 1 = generic form only, 2 = lean form only (the kernel instantiation was chosen on the host), 3 = both, chosen at run
+// time from ConvParams::simple (conv_mfma v1, whose many instantiations are not multiplied again)
+template <int NTX, bool BIAS_IN_ACC = false, int MODE = 3>
 __device__ __forceinline__ void epilogue_simple_rows(const ConvParams& p, f32x16 (&acc)[2][NTX], const float* bias64,
                                                      unsigned char* ew, int n, int cbase, int oy_first, int ox_first,
                                                      int lane, bool zero_acc, bool full = false) {
+  if constexpr (MODE == 2) {
+    epilogue_lean_seq<NTX, BIAS_IN_ACC>(p, acc, bias64, ew, n, cbase, oy_first, ox_first, lane, zero_acc, full);
+    return;
+  }
+  if constexpr (MODE == 3) {
+    if (p.simple == 2) {                 // wave-uniform
+      epilogue_lean_seq<NTX, BIAS_IN_ACC>(p, acc, bias64, ew, n, cbase, oy_first, ox_first, lane, zero_acc, full);
+      return;
+    }
+  }
   PackedRow rows[NTX];
   epilogue_pack<NTX, BIAS_IN_ACC>(p, acc, bias64, lane, rows, zero_acc);
 #pragma unroll

@@ -333,7 +333,7 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
   const int tiles = cout_tiles(d->cout);
   const int mt = tiles == 1 ? 1 : 2;
   if (mt == 2 && convk::conv_is_simple(p)) {
-    p.simple = 1;
+    p.simple = convk::conv_is_lean(p) ? 2 : 1;       // 2: the lean packed-fp16 form of the transposed epilogue (conv_common.h)
     p.slope = convk::conv_simple_slope(p);
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

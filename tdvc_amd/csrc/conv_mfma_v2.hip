@@ -29,7 +29,7 @@ constexpr int WSLICE = 4096;   // bytes of one (cout-block, chunk, tap) weight s
 static long long* g_stamp_buf = nullptr;
 static int g_stamp_cap = 0;
 
-template <bool SIMPLE, bool STAMP = false>
+template <int SIMPLE, bool STAMP = false>      // 0: per-register epilogue4, 1: transposed generic, 2: transposed lean
 __global__ __launch_bounds__(256, 2) void conv_mfma_v2_kernel(const ConvParams p, long long* stamps = nullptr, int stamp_cap = 0) {
   long long st[8];
   int nst = 0;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v2_kernel(const ConvParams p
     // through a wave-private LDS region (the tile buffer is free after the last barrier), then every
     // lane owns 8 consecutive channels of a pixel: residuals and the output move as full 128-byte lines
     // (8 lanes x 16 B per pixel) instead of 32 partial-line requests per store instruction.
-    convk::epilogue_simple_rows<NT>(p, acc, p.bias + cb * 64, tbuf + wave * (32 * 144), n, cb * 64,
+    convk::epilogue_simple_rows<NT, false, SIMPLE>(p, acc, p.bias + cb * 64, tbuf + wave * (32 * 144), n, cb * 64,
                                      ty * TH2 + wave * NT, tx * TW2, lane, false);
   } else {
     const int ox = tx * TW2 + r;
@@ -179,17 +179,21 @@ int launch_conv_v2(const ConvParams& p, int ntiles_unused, int cout_blocks, int 
   hipError_t err = hipSuccess;
   static bool attr_done = false;
   if (!attr_done) {
-    err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (err == hipSuccess)
-      err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (err == hipSuccess)
+      err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (err != hipSuccess) { tdvc_set_error("conv v2: hipFuncSetAttribute failed: %s", hipGetErrorString(err)); return (int)err; }
     attr_done = true;
   }
+  const bool lean = simple && convk::conv_is_lean(p);
   if (g_stamp_buf && simple) {
     static bool a2 = false;
-    if (!a2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v2_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); a2 = true; }
-    hipLaunchKernelGGL((conv_mfma_v2_kernel<true, true>), grid, dim3(256), lds, st, q, g_stamp_buf, g_stamp_cap);
-  } else if (simple) hipLaunchKernelGGL((conv_mfma_v2_kernel<true>), grid, dim3(256), lds, st, q, (long long*)nullptr, 0);
-  else hipLaunchKernelGGL((conv_mfma_v2_kernel<false>), grid, dim3(256), lds, st, q, (long long*)nullptr, 0);
+    if (!a2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v2_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); a2 = true; }
+    hipLaunchKernelGGL((conv_mfma_v2_kernel<1, true>), grid, dim3(256), lds, st, q, g_stamp_buf, g_stamp_cap);
+  } else if (lean) hipLaunchKernelGGL((conv_mfma_v2_kernel<2>), grid, dim3(256), lds, st, q, (long long*)nullptr, 0);
+  else if (simple) hipLaunchKernelGGL((conv_mfma_v2_kernel<1>), grid, dim3(256), lds, st, q, (long long*)nullptr, 0);
+  else hipLaunchKernelGGL((conv_mfma_v2_kernel<0>), grid, dim3(256), lds, st, q, (long long*)nullptr, 0);
   return tdvc_launch_status("tdvc_conv2d(v2)");
 }

@@ -34,7 +34,7 @@ struct V3Extra {
 static long long* g_stamp3 = nullptr;
 static int g_stamp3_cap = 0;
 
-template <bool SIMPLE, bool STAMP = false>
+template <int SIMPLE, bool STAMP = false>      // 0: per-register epilogue4, 1: transposed generic, 2: transposed lean
 __global__ __launch_bounds__(256, 2) void conv_mfma_v3_kernel(const ConvParams p, const V3Extra e, long long* stamps = nullptr, int stamp_cap = 0) {
   long long stv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define ST3(i) do { if constexpr (STAMP) { if (S == 3) stv[i] = clock64(); } } while (0)
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v3_kernel(const ConvParams p
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     if constexpr (SIMPLE) {
       __syncthreads();                   // the tile buffer becomes per-wave scratch
-      convk::epilogue_simple_rows<NT3>(p, acc, bias_s, tbuf + wave * (32 * 144), n, cb * 64,
+      convk::epilogue_simple_rows<NT3, false, SIMPLE>(p, acc, bias_s, tbuf + wave * (32 * 144), n, cb * 64,
                                        ty * TH3 + wave * NT3, tx * TW3, lane, true);
     } else {
       const int ox = tx * TW3 + r;
@@ -233,17 +233,21 @@ int launch_conv_v3(const ConvParams& p, int cout_blocks, int N, hipStream_t st) 
   dim3 grid(gx, cout_blocks, N);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (err == hipSuccess)
-      err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (err == hipSuccess)
+      err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (err != hipSuccess) { tdvc_set_error("conv v3: hipFuncSetAttribute failed: %s", hipGetErrorString(err)); return (int)err; }
     attr_done = true;
   }
+  const bool lean = simple && convk::conv_is_lean(p);
   if (g_stamp3 && simple) {
     static bool a2 = false;
-    if (!a2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v3_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); a2 = true; }
-    hipLaunchKernelGGL((conv_mfma_v3_kernel<true, true>), grid, dim3(256), lds, st, q, e, g_stamp3, g_stamp3_cap);
-  } else if (simple) hipLaunchKernelGGL((conv_mfma_v3_kernel<true>), grid, dim3(256), lds, st, q, e, (long long*)nullptr, 0);
-  else hipLaunchKernelGGL((conv_mfma_v3_kernel<false>), grid, dim3(256), lds, st, q, e, (long long*)nullptr, 0);
+    if (!a2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v3_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); a2 = true; }
+    hipLaunchKernelGGL((conv_mfma_v3_kernel<1, true>), grid, dim3(256), lds, st, q, e, g_stamp3, g_stamp3_cap);
+  } else if (lean) hipLaunchKernelGGL((conv_mfma_v3_kernel<2>), grid, dim3(256), lds, st, q, e, (long long*)nullptr, 0);
+  else if (simple) hipLaunchKernelGGL((conv_mfma_v3_kernel<1>), grid, dim3(256), lds, st, q, e, (long long*)nullptr, 0);
+  else hipLaunchKernelGGL((conv_mfma_v3_kernel<0>), grid, dim3(256), lds, st, q, e, (long long*)nullptr, 0);
   return tdvc_launch_status("tdvc_conv2d(v3)");
 }

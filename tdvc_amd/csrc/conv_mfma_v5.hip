@@ -29,7 +29,7 @@ struct V5Extra {
 };
 
 // TL = 16-byte loads per lane per stage: 4 for 1x1 (2 x 32 pixels x 4 chunks / 64 lanes)
-template <bool SIMPLE, int TL>
+template <int SIMPLE, int TL>      // SIMPLE 0: per-register epilogue4, 1: transposed generic, 2: transposed lean
 __global__ __launch_bounds__(NTHR5, 1) void conv_mfma_v5_kernel(const ConvParams p, const V5Extra e) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int* tapoff = reinterpret_cast<int*>(smem);
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(NTHR5, 1) void conv_mfma_v5_kernel(const ConvParams
       if constexpr (SIMPLE) {
         // the private tile doubles as the transpose scratch (this wave's reads of it are complete:
         // every fragment read was waited for before its MFMA)
-        convk::epilogue_simple_rows<WR>(p, acc, bias_s, tbuf, n, cb * 64, oy0, tx * TW5, lane, true);
+        convk::epilogue_simple_rows<WR, false, SIMPLE>(p, acc, bias_s, tbuf, n, cb * 64, oy0, tx * TW5, lane, true);
       } else {
         const int ox = tx * TW5 + r;
 #pragma unroll
@@ -194,17 +194,20 @@ inline int v5_lds_bytes(int kh, int kw, int ntaps, int nchunks) { return 512 + n
 inline int v5_tl(int kh, int kw) { return ((WR + kh - 1) * (TW5 + kw - 1) * 4 + 63) / 64; }
 
 template <int TL>
-int launch_tl(const ConvParams& q, const V5Extra& e, bool simple, dim3 grid, int lds, hipStream_t st) {
+int launch_tl(const ConvParams& q, const V5Extra& e, int mode, dim3 grid, int lds, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v5_kernel<true, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v5_kernel<1, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err == hipSuccess)
-      err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v5_kernel<false, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v5_kernel<2, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (err == hipSuccess)
+      err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v5_kernel<0, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err != hipSuccess) { tdvc_set_error("conv v5: hipFuncSetAttribute failed: %s", hipGetErrorString(err)); return (int)err; }
     attr_done = true;
   }
-  if (simple) hipLaunchKernelGGL((conv_mfma_v5_kernel<true, TL>), grid, dim3(NTHR5), lds, st, q, e);
-  else hipLaunchKernelGGL((conv_mfma_v5_kernel<false, TL>), grid, dim3(NTHR5), lds, st, q, e);
+  if (mode == 2) hipLaunchKernelGGL((conv_mfma_v5_kernel<2, TL>), grid, dim3(NTHR5), lds, st, q, e);
+  else if (mode == 1) hipLaunchKernelGGL((conv_mfma_v5_kernel<1, TL>), grid, dim3(NTHR5), lds, st, q, e);
+  else hipLaunchKernelGGL((conv_mfma_v5_kernel<0, TL>), grid, dim3(NTHR5), lds, st, q, e);
   return tdvc_launch_status("tdvc_conv2d(v5)");
 }
 
@@ -237,7 +240,7 @@ int launch_conv_v5(const ConvParams& p, int cout_blocks, int N, hipStream_t st) 
   if (gx > e.nbtiles) gx = e.nbtiles;
   dim3 grid(gx, cout_blocks, N);
   const int tl = v5_tl(p.kh, p.kw);
-  if (tl == 4) return launch_tl<4>(q, e, simple, grid, lds, st);
+  if (tl == 4) return launch_tl<4>(q, e, simple ? (convk::conv_is_lean(p) ? 2 : 1) : 0, grid, lds, st);
   tdvc_set_error("conv v5: unsupported window %dx%d", p.kh, p.kw);
   return TDVC_EINVAL;
 }

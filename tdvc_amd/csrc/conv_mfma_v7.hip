@@ -216,7 +216,7 @@ __global__ __launch_bounds__(NTHR7, 1) void conv_mfma_v7_kernel(const ConvParams
     const bool full = (ty + 1) * TH7 <= p.Ho && (tx + 1) * TW7 <= p.Wo;
     raw_barrier();                       // all waves finished reading this tile buffer: it becomes epilogue scratch
     ST7(4);
-    convk::epilogue_simple_rows<NT7, true>(p, acc, bias_s, smem + bsel + wave * (32 * 144), n, cb * 64,
+    convk::epilogue_simple_rows<NT7, true, 1>(p, acc, bias_s, smem + bsel + wave * (32 * 144), n, cb * 64,
                                            ty * TH7 + wave * NT7, tx * TW7, lane, false, full);
     init_acc();
     stores_in_flight = full;
