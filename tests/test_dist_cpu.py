@@ -101,3 +101,48 @@ def test_gradient_buckets_all_reduce_mean():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok and views and zeroed and nb >= 2
+
+
+def _sweep_worker(rank, world, port, q):
+    """cfg-5 sweep: (lambda, GOP) items dealt round-robin, per-frame rows gathered, one table on rank 0"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tdvc_amd.tools.rd_sweep import assemble_table, work_items
+    lams = (256, 512, 1024, 2048)
+    stats = [{"lambda": lam, "gop": g, "frame": f, "bpp": 1.0 / lam + 0.001 * g, "psnr": 30.0 + lam / 1024.0, "msssim": float("nan") if f == 1 else 0.9}
+             for lam, g in work_items(lams, 3, world, rank) for f in (1, 2)]
+    allstats = gather_frame_stats(stats)
+    if rank == 0:
+        q.put((work_items(lams, 3, world, rank), assemble_table(allstats, lams)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rd_sweep_partition_and_table(tmp_path):
+    from tdvc_amd.tools import rd_sweep
+    lams = (256, 512, 1024, 2048)
+    items = [rd_sweep.work_items(lams, 3, 8, r) for r in range(8)]
+    assert sorted(sum(items, [])) == sorted((l, g) for l in lams for g in range(3))       # every (lambda, GOP) exactly once
+    assert max(len(i) for i in items) - min(len(i) for i in items) <= 1                  # 12 items over 8 ranks: balanced
+    assert rd_sweep.lambda_from_name("/x/y/40000_lambda2048.pth") == 2048                 # tools/predict.py:131
+    import pytest
+    with pytest.raises(ValueError):
+        rd_sweep.lambda_from_name("latest.pth")
+    for n in ("10000_lambda256.pth", "20000_lambda256.pth", "10000_lambda1024.pth", "latest.pth"):
+        (tmp_path / n).write_bytes(b"")
+    ck = rd_sweep.find_checkpoints(str(tmp_path), lams)
+    assert ck[256].endswith("20000_lambda256.pth") and ck[1024].endswith("10000_lambda1024.pth") and ck[512] is None and ck[2048] is None
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_sweep_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    mine, rows = q.get(timeout=120)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(mine) == 6
+    assert [r["lambda"] for r in rows] == list(lams) and all(r["frames"] == 6 for r in rows)
+    assert abs(rows[0]["bpp"] - (1.0 / 256 + 0.001)) < 1e-9 and abs(rows[3]["psnr"] - 32.0) < 1e-9
+    assert all(abs(r["msssim"] - 0.9) < 1e-12 for r in rows)                               # NaN rows (frames under 176 px) are left out of the mean

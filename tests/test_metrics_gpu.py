@@ -94,3 +94,22 @@ def test_predict_tool_on_a_dataset_tree(tmp_path, report):
     txt = open(out).read()
     assert "msssim : " in txt and "bpp : " in txt and "psnr : " in txt
     report(f"predict tool on a class-D tree: {res['frames']} frames, bpp {res['bpp']:.4f}, psnr {res['psnr']:.3f}, ms-ssim {res['msssim']:.5f}")
+
+
+def test_rd_sweep_tool(report):
+    """BASELINE configs[4] driver: lambda list x GOP shards -> one BPP / PSNR / MS-SSIM table (single rank here; the rank
+    partition and the gather are covered on gloo in tests/test_dist_cpu.py)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "tdvc_amd.tools.rd_sweep", "--lambdas", "256", "2048", "--gops", "2", "--gop-size", "3",
+                          "--height", "192", "--width", "256"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.splitlines()[0])
+    rows = res["curve"]
+    report(f"rd_sweep: {rows}")
+    assert [r["lambda"] for r in rows] == [256, 2048] and all(r["frames"] == 4 for r in rows)
+    assert all(r["bpp"] > 0 and 5.0 < r["psnr"] < 60.0 and 0.0 < r["msssim"] <= 1.0 for r in rows)
+    assert rows[0]["bpp"] == rows[1]["bpp"]            # no checkpoints: the same filler weights code both lambdas
