@@ -16,6 +16,7 @@ struct ConvParams {
   int tiles_x;
   int simple;           // host decision: transposed fast epilogue (conv_is_simple)
   int s2d, Corig;       // space-to-depth view of a stride-2 conv (v3 only): Corig = channels per parity
+  int reverse;          // walk the tile raster backwards (alternate launches: see tdvc_conv2d, "Infinity Cache")
   int8_t tap_dy[TDVC_MAX_TAPS], tap_dx[TDVC_MAX_TAPS];
 };
 

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, r = lane & 31;
-  const int tile_id = tdvc_xcd_tile(blockIdx.x);
+  const int tile_id = p.reverse ? (int)gridDim.x - 1 - tdvc_xcd_tile(blockIdx.x) : tdvc_xcd_tile(blockIdx.x);
   const int tx = tile_id % p.tiles_x, ty = tile_id / p.tiles_x;
   const int cb = blockIdx.y, n = blockIdx.z;
 
@@ -252,6 +252,20 @@ extern "C" int tdvc_pack_conv_weights(const float* w, int cout, int cin_real, in
 
 static thread_local char g_last_kernel[48] = "";
 
+// Tile-walk direction.  The 256 MB Infinity Cache sits in front of HBM and every layer streams a map slightly larger
+// than it (64 channels x 1088 x 1920 fp16 = 267 MB): when layer l+1 reads, in the same raster order, what layer l just
+// wrote, the head of the map has already been pushed out by its tail and nothing hits.  Consecutive launches therefore
+// walk the tile raster in OPPOSITE directions: the consumer starts on the producer's most recently written tiles (and on
+// the tail of the residual the producer read), which are still resident.  Launch parity is per host thread (one stream
+// of launches per rank); any order is correct, the alternation only decides what hits.
+static thread_local unsigned g_walk_parity = 0;
+static int g_walk_mode = -1;      // -1: read TDVC_CONV_WALK once (0 = always forward, 1 = alternate [default])
+extern "C" void tdvc_debug_set_conv_walk(int mode) { g_walk_mode = mode; }
+static int next_walk_reverse() {
+  if (g_walk_mode < 0) { const char* e = getenv("TDVC_CONV_WALK"); g_walk_mode = e ? atoi(e) : 1; }
+  return g_walk_mode == 1 ? (int)(g_walk_parity++ & 1u) : 0;
+}
+
 extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
   TDVC_CHECK(d, "tdvc_conv2d: null descriptor");
   if (d->x.dtype == TDVC_F32) {           // fp32 islands (pnet.py:33,57): fp32 activations + fp32 packing -> conv_f32.hip
@@ -330,6 +344,7 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
   memcpy(p.tap_dx, d->tap_dx, sizeof(p.tap_dx));
   const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
   p.tiles_x = tiles_x;
+  p.reverse = next_walk_reverse();
   const int tiles = cout_tiles(d->cout);
   const int mt = tiles == 1 ? 1 : 2;
   if (mt == 2 && convk::conv_is_simple(p)) {

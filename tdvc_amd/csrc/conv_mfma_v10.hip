@@ -117,7 +117,9 @@ __global__ __launch_bounds__(NTHR10, 1) void conv_mfma_v10_kernel(const ConvPara
   };
 
   // ---- prologue: first tile's DMA, then bias + resident weights (compiler-tracked loads, younger than the DMA)
-  int ty = first / p.tiles_x, tx = first - ty * p.tiles_x;   // the tile being computed
+  const int tile0 = p.reverse ? e.ntiles - 1 - first : first;   // alternate launches walk the raster backwards (tdvc_conv2d)
+  const int tstep = p.reverse ? -stride : stride;
+  int ty = tile0 / p.tiles_x, tx = tile0 - ty * p.tiles_x;      // the tile being computed
   issue_prep(ty, tx, 0);
 #pragma unroll
   for (int j = 0; j < DMA10; ++j) issue_one(j, lds0);
@@ -188,8 +190,9 @@ __global__ __launch_bounds__(NTHR10, 1) void conv_mfma_v10_kernel(const ConvPara
 
   for (int ti = 0; ti < my_tiles; ++ti) {
     const bool last_tile = ti + 1 == my_tiles;
-    int nty = ty, ntx = tx + stride;     // the next tile of this workgroup
+    int nty = ty, ntx = tx + tstep;      // the next tile of this workgroup
     while (ntx >= p.tiles_x) { ntx -= p.tiles_x; ++nty; }
+    while (ntx < 0) { ntx += p.tiles_x; --nty; }
 
     auto stage = [&](auto CH) {
       constexpr int ch = decltype(CH)::value;

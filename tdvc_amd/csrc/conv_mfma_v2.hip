@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v2_kernel(const ConvParams p
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, r = lane & 31;
-  const int tile_id = tdvc_xcd_tile(blockIdx.x);
+  const int tile_id = p.reverse ? (int)gridDim.x - 1 - tdvc_xcd_tile(blockIdx.x) : tdvc_xcd_tile(blockIdx.x);
   const int tx = tile_id % p.tiles_x, ty = tile_id / p.tiles_x;
   const int cb = blockIdx.y, n = blockIdx.z;
   const int TIW = TW2 + p.kw - 1;

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v3_kernel(const ConvParams p
   half8 treg[TLOADS], wreg[WLOADS];
   auto issue = [&](int S) {
     const int tile_i = S / nchunks, ch = S - tile_i * nchunks;
-    const int tile = first + tile_i * stride;
+    const int tile = p.reverse ? e.ntiles - 1 - (first + tile_i * stride) : first + tile_i * stride;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     const int iy0 = ty * TH3 - p.pad, ix0 = tx * TW3 - p.pad;
     int cg = ch * CK3 + c8off;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v3_kernel(const ConvParams p
     }
     if (ch != nchunks - 1) continue;
     // ---- tile finished: epilogue -----------------------------------------------------------------
-    const int tile = first + tile_i * stride;
+    const int tile = p.reverse ? e.ntiles - 1 - (first + tile_i * stride) : first + tile_i * stride;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     if constexpr (SIMPLE) {
       __syncthreads();                   // the tile buffer becomes per-wave scratch

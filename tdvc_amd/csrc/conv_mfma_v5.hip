@@ -80,7 +80,7 @@ __global__ __launch_bounds__(NTHR5, 1) void conv_mfma_v5_kernel(const ConvParams
   auto issue = [&](auto setc, int S) {
     constexpr int SET = decltype(setc)::value;
     const int tile_i = S / nchunks, ch = S - tile_i * nchunks;
-    const int tile = first + tile_i * stride;
+    const int tile = p.reverse ? e.nbtiles - 1 - (first + tile_i * stride) : first + tile_i * stride;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     const int iy0 = ty * (WR * NWAVE) + wave * WR - p.pad, ix0 = tx * TW5 - p.pad;
     const int cg = ch * CK5 + c8off;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(NTHR5, 1) void conv_mfma_v5_kernel(const ConvParams
     }
 
     if (ch == nchunks - 1) {
-      const int tile = first + tile_i * stride;
+      const int tile = p.reverse ? e.nbtiles - 1 - (first + tile_i * stride) : first + tile_i * stride;
       const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
       const int oy0 = ty * (WR * NWAVE) + wave * WR;
       if constexpr (SIMPLE) {

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(NTHR7, 1) void conv_mfma_v7_kernel(const ConvParams
   const half_t* pf_base = xn;
   auto issue_prep = [&](int S) {
     const int tile_i = S / nchunks, ch = S - tile_i * nchunks;
-    const int tile = first + tile_i * stride;
+    const int tile = p.reverse ? e.ntiles - 1 - (first + tile_i * stride) : first + tile_i * stride;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     pf_iy0 = ty * TH7 - 1;
     pf_ix0 = tx * TW7 - 1;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(NTHR7, 1) void conv_mfma_v7_kernel(const ConvParams
     stores_in_flight = false;
     if (ch != nchunks - 1) continue;
 
-    const int tile = first + tile_i * stride;
+    const int tile = p.reverse ? e.ntiles - 1 - (first + tile_i * stride) : first + tile_i * stride;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     const bool full = (ty + 1) * TH7 <= p.Ho && (tx + 1) * TW7 <= p.Wo;
     raw_barrier();                       // all waves finished reading this tile buffer: it becomes epilogue scratch
