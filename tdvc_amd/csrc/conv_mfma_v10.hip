@@ -147,23 +147,19 @@ __global__ __launch_bounds__(NTHR10, 1) void conv_mfma_v10_kernel(const ConvPara
 
   __syncthreads();                       // bias and weights are visible (no DMA-aware wait here: see top of stage)
 
+  // Accumulators are never re-initialised: the first MFMA of every accumulator chain in a tile (stage 0, group 0, dy of its
+  // first visit) takes the bias vector as its C operand.  bias16[mt] holds, per lane, the 16 biases of the accumulator rows
+  // (channels mt*32 + 8g + 4hh + i) and stays in registers for the whole launch.
   f32x16 acc[2][NT10];
-  auto init_acc = [&]() {                // accumulators start from the bias: LDS reads, no vector moves
+  f32x16 bias16[2];
 #pragma unroll
-    for (int nt = 0; nt < NT10; ++nt) {
-      int o = hh * 4;
-      asm volatile("" : "+v"(o));        // keep one read per accumulator (no register copies)
+  for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + mt * 32 + 8 * g + hh * 4);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + mt * 32 + 8 * g + o);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[mt][nt][4 * g + i] = b4[i];
-        }
+      for (int i = 0; i < 4; ++i) bias16[mt][4 * g + i] = b4[i];
     }
-  };
-  init_acc();
 
   // ---- epilogue state.  Every CU moves ~10 B per cycle to / from HBM: a tile's 64 KB of residual reads and 64 KB of
   // stores issued as one burst after the matrix phase cost 6-7 k cycles each in which no MFMA runs (stamps).
@@ -209,30 +205,43 @@ __global__ __launch_bounds__(NTHR10, 1) void conv_mfma_v10_kernel(const ConvPara
       if constexpr (ch == 1) {           // this tile's output geometry + residual prefetch (consumed by the epilogue below)
         const int oy = ty * TH10 + wave * NT10, ox_first = tx * TW10;
         const bool full = (ty + 1) * TH10 <= p.Ho && (tx + 1) * TW10 <= p.Wo;
-        cur_mask = 0;
+        if (full) {                      // wave-uniform: 94 % of the tiles at 1080p -- two adds per pixel group, no compares
+          const int base = oy * p.Wo + ox_first + prow;
+#pragma unroll
+          for (int j = 0; j < NT10; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cur_opix[j][k] = ch_ok ? base + j * p.Wo + k * 8 : 0;
+          cur_mask = ch_ok ? 0xFFFFu : 0u;
+        } else {
+          cur_mask = 0;
+#pragma unroll
+          for (int j = 0; j < NT10; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int ox = ox_first + k * 8 + prow;
+              const bool ok = ch_ok && oy + j < p.Ho && ox < p.Wo;
+              cur_opix[j][k] = ok ? (oy + j) * p.Wo + ox : 0;
+              cur_mask |= ok ? (1u << (j * 4 + k)) : 0u;
+            }
+        }
+      }
+      // the residual rows of this tile, all at the start of its second stage, when this wave has nothing outstanding (just
+      // after vmcnt(0)): one row per matrix group was tried and is SLOWER (14.2 k -> 20.6 k cycles for stage + epilogue) -- behind
+      // four DMA pieces and eight loads the next loads wait ~3 k cycles at issue: a wave keeps only ~12-16 vector-memory
+      // instructions in flight
+      if constexpr (ch == 1 && NRES >= 1) {
+        const half_t* rb = reinterpret_cast<const half_t*>(p.res.p) + (long)n * p.res.sn + ccl;
 #pragma unroll
         for (int j = 0; j < NT10; ++j)
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int ox = ox_first + k * 8 + prow;
-            const bool ok = full ? ch_ok : (ch_ok && oy + j < p.Ho && ox < p.Wo);
-            cur_opix[j][k] = ok ? (oy + j) * p.Wo + ox : 0;
-            cur_mask |= ok ? (1u << (j * 4 + k)) : 0u;
-          }
-        if constexpr (NRES >= 1) {
-          const half_t* rb = reinterpret_cast<const half_t*>(p.res.p) + (long)n * p.res.sn + ccl;
+          for (int k = 0; k < 4; ++k) r1[j][k] = *reinterpret_cast<const half8*>(rb + (long)cur_opix[j][k] * p.res.sp);
+      }
+      if constexpr (ch == 1 && NRES >= 2) {
+        const half_t* rb = reinterpret_cast<const half_t*>(p.res2.p) + (long)n * p.res2.sn + ccl;
 #pragma unroll
-          for (int j = 0; j < NT10; ++j)
+        for (int j = 0; j < NT10; ++j)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) r1[j][k] = *reinterpret_cast<const half8*>(rb + (long)cur_opix[j][k] * p.res.sp);
-        }
-        if constexpr (NRES >= 2) {
-          const half_t* rb = reinterpret_cast<const half_t*>(p.res2.p) + (long)n * p.res2.sn + ccl;
-#pragma unroll
-          for (int j = 0; j < NT10; ++j)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) r2[j][k] = *reinterpret_cast<const half8*>(rb + (long)cur_opix[j][k] * p.res2.sp);
-        }
+          for (int k = 0; k < 4; ++k) r2[j][k] = *reinterpret_cast<const half8*>(rb + (long)cur_opix[j][k] * p.res2.sp);
       }
 
       // matrix phase: 6 groups (s2, dx) of 24 MFMAs; group g+1's 12 fragment reads are issued under group g's MFMAs
@@ -264,9 +273,11 @@ __global__ __launch_bounds__(NTHR10, 1) void conv_mfma_v10_kernel(const ConvPara
           for (int dy = 0; dy < 3; ++dy) {
             const int nt = ir - dy;
             if (nt >= 0 && nt < NT10) {
+              // the chain of acc[.][nt] starts at (stage 0, group 0) with its smallest dy, i.e. dy == 0 (ir == nt)
+              const bool first = ch == 0 && g == 0 && dy == 0;
 #pragma unroll
               for (int mt = 0; mt < 2; ++mt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][dy][mt], fb[g & 1][ir], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][dy][mt], fb[g & 1][ir], first ? bias16[mt] : acc[mt][nt], 0, 0, 0);
             }
           }
         // pin the software pipeline: one fragment read of group g+1 per two MFMAs of group g
@@ -335,7 +346,6 @@ __global__ __launch_bounds__(NTHR10, 1) void conv_mfma_v10_kernel(const ConvPara
           }
       }
       pend_mask = cur_mask;
-      init_acc();
       ST10(5);
       if constexpr (STAMP) {
         if (ti == 1 && lane == 0) {          // one record per wave: [block][wave][24 stamps]
