@@ -122,6 +122,9 @@ typedef struct {
   const float* bias;
   int32_t groups;
   int32_t act; float slope; int32_t round_before_act;
+  void* x_planar;       /* optional scratch of N*H*W*8*groups fp16 values (ABI v2): when non-NULL, x is first re-laid
+                           group-planar ([n][g][H][W][8]) and the bilinear gathers read that copy (neighbouring pixels of a
+                           group share 128-byte lines); NULL: gather from the NHWC map */
 } tdvc_dcn_desc;
 int tdvc_dcn_fused(const tdvc_dcn_desc* d, void* stream);
 

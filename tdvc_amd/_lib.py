@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
 
 class DcnDesc(C.Structure):
     _fields_ = [("x", FMapDesc), ("om", FMapDesc), ("y", FMapDesc), ("w", C.c_void_p), ("bias", C.c_void_p),
-                ("groups", C.c_int32), ("act", C.c_int32), ("slope", C.c_float), ("round_before_act", C.c_int32)]
+                ("groups", C.c_int32), ("act", C.c_int32), ("slope", C.c_float), ("round_before_act", C.c_int32), ("x_planar", C.c_void_p)]
 
 
 _P = C.c_void_p

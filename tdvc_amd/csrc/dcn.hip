@@ -17,7 +17,20 @@ struct DcnParams {
   const half_t* w; const float* bias;
   int G; int act; float slope; int round16;
   long npix;   // H*W
+  const half_t* xp;   // group-planar copy of x ([N][G][H][W][8]) or null
 };
+
+// x (NHWC, 8G channels) -> [n][g][H][W][8]: 8 lanes read one pixel's 128-byte line, every group plane receives 128
+// contiguous bytes per 8 pixels
+__global__ void dcn_planarise_kernel(const half_t* x, long x_sn, int x_sp, long npix, int G, half_t* xp) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = blockIdx.y;
+  if (i >= npix * G) return;
+  const int g = (int)(i % G);
+  const long pix = i / G;
+  const half8 v = *reinterpret_cast<const half8*>(x + (long)n * x_sn + pix * x_sp + g * 8);
+  *reinterpret_cast<half8*>(xp + (((long)n * G + g) * npix + pix) * 8) = v;
+}
 
 // Fused kernel, 3x3 / stride 1 / pad 1 / dilation 1, 8 channels per deformable group.
 // One 256-thread workgroup = an 8x8 pixel tile x all 8G output channels.
@@ -73,6 +86,11 @@ __global__ __launch_bounds__(256) void dcn_fused_kernel(const DcnParams p) {
   const int g = tid & 7;
   const bool g_on = g < G;
   const int gg = g_on ? g : 0;
+  // gather source of this thread's group: the NHWC map (pixel stride x_sp: every 16-byte corner of every lane is a line
+  // of its own -- the L1 takes one line per clock, profiles/r01_dcn_fused_1080p_pmc.txt) or the group-planar copy
+  // [n][g][H][W][8] (pixel stride 8: the 8 lanes of a group sample 8 neighbouring pixels, whose corners share lines)
+  const half_t* xg = p.xp ? p.xp + ((long)n * G + gg) * p.npix * 8 : xn + gg * 8;
+  const int xsp = p.xp ? 8 : p.x_sp;
   int soy[2], sox[2];
   half2v off[2][9];
   float msk[2][9];
@@ -108,7 +126,7 @@ __global__ __launch_bounds__(256) void dcn_fused_kernel(const DcnParams p) {
           const half2v o2 = off[ps][chunk * 3 + tc];
           const float h_im = (float)(soy[ps] - 1 + chunk) + (float)o2[0];      // tap = chunk*3 + tc: dy = chunk, dx = tc
           const float w_im = (float)(sox[ps] - 1 + tc) + (float)o2[1];
-          const half8 v = sample8_bf(xn + gg * 8, p.H, p.W, p.x_sp, h_im, w_im, msk[ps][chunk * 3 + tc]);
+          const half8 v = sample8_bf(xg, p.H, p.W, xsp, h_im, w_im, msk[ps][chunk * 3 + tc]);
           const int pl = (tid >> 3) + 32 * ps;
           *reinterpret_cast<half8*>(col + pl * PS + tc * G * 16 + gg * 16) = v;
         }
@@ -249,6 +267,13 @@ extern "C" int tdvc_dcn_fused(const tdvc_dcn_desc* d, void* stream) {
   p.w = reinterpret_cast<const half_t*>(d->w); p.bias = d->bias;
   p.G = G; p.act = d->act; p.slope = d->slope; p.round16 = d->round_before_act;
   p.npix = (long)d->x.H * d->x.W;
+  p.xp = reinterpret_cast<const half_t*>(d->x_planar);
+  if (p.xp) {
+    TDVC_CHECK(aligned16(d->x_planar), "tdvc_dcn_fused: x_planar scratch unaligned");
+    const long items = p.npix * G;
+    hipLaunchKernelGGL(dcn_planarise_kernel, dim3((unsigned)((items + 255) / 256), d->x.N), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       p.x, p.x_sn, p.x_sp, p.npix, G, reinterpret_cast<half_t*>(d->x_planar));
+  }
   dim3 grid((unsigned)(((d->x.W + DCN_TPX - 1) / DCN_TPX) * ((d->x.H + DCN_TPY - 1) / DCN_TPY)), d->x.N);
   const size_t lds = (size_t)64 * (DCN_TAPS_PER_CHUNK * G * 16 + 16);
   hipLaunchKernelGGL(dcn_fused_kernel, grid, dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);

@@ -13,5 +13,5 @@ void tdvc_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int tdvc_abi_version(void) { return 1; }
+extern "C" int tdvc_abi_version(void) { return 2; }   // 2: tdvc_dcn_desc.x_planar, fp32 conv entry points
 extern "C" const char* tdvc_last_error(void) { return g_err; }

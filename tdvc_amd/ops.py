@@ -605,11 +605,21 @@ def upsample2x_backward(dy: FM, dx: FM) -> None:
     L.check(L.lib().tdvc_upsample2x_backward(C.byref(d1), C.byref(d2), _stream()), "upsample2x_backward")
 
 
-def dcn_fused(x: FM, om: FM, pc: PackedConv, out: FM, groups=8, act=ACT_NONE, slope=0.0, round16=True) -> FM:
+DCN_PLANAR_MIN_PIXELS = 1 << 16      # below this the map is L2-resident anyway and the extra pass does not pay
+DCN_PLANAR = __import__("os").environ.get("TDVC_DCN_PLANAR", "0") == "1"
+
+
+def dcn_fused(x: FM, om: FM, pc: PackedConv, out: FM, groups=8, act=ACT_NONE, slope=0.0, round16=True, planar: bool | None = None) -> FM:
+    """`planar` (default: large maps): gather from a group-planar copy of x made by the same call (one extra pass over x;
+    the 288 bilinear corner gathers per pixel then share 128-byte lines between neighbouring pixels of a group)"""
     d = L.DcnDesc()
     d.x, d.om, d.y = x.desc(), om.desc(), out.desc()
     d.w, d.bias = pc.w.data_ptr(), pc.bias.data_ptr()
     d.groups, d.act, d.slope, d.round_before_act = groups, act, slope, int(round16)
+    if planar is None:
+        planar = DCN_PLANAR and x.H * x.W >= DCN_PLANAR_MIN_PIXELS
+    scratch = torch.empty((x.N, groups, x.H, x.W, 8), dtype=torch.float16, device=x.t.device) if planar else None
+    d.x_planar = scratch.data_ptr() if scratch is not None else None
     L.check(L.lib().tdvc_dcn_fused(C.byref(d), _stream()), "dcn_fused")
     _rec("dcn_fused", x, om, pc, out, groups, act, slope)
     return out

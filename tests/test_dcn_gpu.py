@@ -94,6 +94,14 @@ def test_fused_dcn_vs_oracle(H, W, report):
     dst = ops.FM.empty(2, H, W, 64)
     m.run(to_fm(x, ops), to_fm(y, ops), dst, act=ops.ACT_LRELU, slope=0.1)
     assert_close(fm_to_cpu(dst), want, 4e-3, 4e-3, f"fused DCN {H}x{W}", report)
+    # the group-planar gather (default on large maps: one extra pass over x, corners of neighbouring pixels share lines)
+    # samples the same values with the same arithmetic: bit-identical output
+    om_fm = ops.conv(to_fm(y, ops), ops.pack_conv(m.conv_offset_mask.weight, m.conv_offset_mask.bias, stride=1, pad=1))
+    pc = ops.pack_conv(m.weight, m.bias, stride=1, pad=1, ck=64)
+    a, b = ops.FM.empty(2, H, W, 64), ops.FM.empty(2, H, W, 64)
+    ops.dcn_fused(to_fm(x, ops), om_fm, pc, a, groups=8, act=ops.ACT_LRELU, slope=0.1, planar=False)
+    ops.dcn_fused(to_fm(x, ops), om_fm, pc, b, groups=8, act=ops.ACT_LRELU, slope=0.1, planar=True)
+    assert torch.equal(a.t, b.t) and torch.equal(a.t, dst.t), "group-planar gather differs from the NHWC gather"
 
 
 @pytest.mark.parametrize("cfg", [
