@@ -26,6 +26,8 @@ int launch_conv_v5(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
 bool conv_v5_eligible(const tdvc_conv_desc* d, int Ho, int Wo);
 int launch_conv_v7(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
 bool conv_v7_eligible(const tdvc_conv_desc* d, const ConvParams& p, int Ho, int Wo);
+int launch_conv_v11(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
+bool conv_v11_eligible(const tdvc_conv_desc* d, const ConvParams& p, int Ho, int Wo);
 int launch_conv_v10(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
 bool conv_v10_eligible(const tdvc_conv_desc* d, const ConvParams& p, int Ho, int Wo);
 int launch_conv_v9(const ConvParams& p, int ck8, int cout_tiles32, int N, hipStream_t st);
@@ -362,6 +364,7 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
   if (conv_v5_eligible(d, Ho, Wo)) { chose("conv_mfma_v5"); return launch_conv_v5(p, tiles / 2, d->x.N, st); }
   if (conv_v10_eligible(d, p, Ho, Wo)) { chose("conv_mfma_v10"); return launch_conv_v10(p, tiles / 2, d->x.N, st); }
   if (conv_v7_eligible(d, p, Ho, Wo)) { chose("conv_mfma_v7"); return launch_conv_v7(p, tiles / 2, d->x.N, st); }
+  if (conv_v11_eligible(d, p, Ho, Wo)) { chose("conv_mfma_v11"); return launch_conv_v11(p, tiles / 2, d->x.N, st); }
   if (conv_v3_eligible(d, Ho, Wo)) { chose("conv_mfma_v3"); return launch_conv_v3(p, tiles / 2, d->x.N, st); }
   if (conv_v2_eligible(d, Ho, Wo)) { chose("conv_mfma_v2"); return launch_conv_v2(p, 0, tiles / 2, d->x.N, st); }
   TDVC_CHECK(lds <= 64 * 1024, "tdvc_conv2d: LDS plan %d bytes too large for the direct kernel (use tdvc_conv_plan)", lds);

@@ -1,0 +1,305 @@
+// conv_mfma_v11 — 3x3, stride 1, pad 1, Cin a multiple of 32 with Cin >= 128 (the 128->128 / 128->64 convs of the coders, MCNet
+// and the in-loop filter: 7.7 ms per 1080p frame on conv_mfma_v3 at 0.27-0.29 of the MFMA peak), Cout >= 64, lean epilogue
+// (fp16 NHWC, no GDN / PixelShuffle).
+//
+// These layers are compute-bound (575 FLOP/B at 128->128) but cannot be weight-stationary: 64 couts x 128 cin x 9 taps is
+// 144 KB.  v3 stages tile AND weights of every 32-channel stage global -> VGPR -> LDS (measured: 4.3 k cycles of load-issue
+// back-pressure per 5 k-cycle stage).  v11 keeps v7's pipeline and lets the LDS-DMA carry both:
+//   * a stage = one 32-channel chunk of a 16x32-px tile (39 KB halo image, XOR-swizzled as in v7) + the 64-cout weight
+//     slice of that chunk (36 KB = 2 cout tiles x 18 k-steps x 1 KB, already in MFMA fragment order in global memory, so
+//     a DMA piece IS a fragment); two stage buffers (2 x 76 KB); stage S+1 streams in during stage S's matrix phase:
+//     75 pieces over 8 waves, hidden behind the partner wave of each SIMD;
+//   * 8 waves = 2 cout tiles x 4 row groups; a wave computes 32 couts x (4 rows x 32 px): four accumulators, and for a
+//     fixed (k-half, dx) the B fragment of input row ir serves output rows ir, ir-1, ir-2: 3 A + 6 B reads per 12 MFMAs
+//     (0.75 LDS reads per MFMA; v3 / v7: 1.0);
+//   * bias as the C operand of each accumulator chain's first MFMA; lean packed-fp16 epilogue through the finished tile
+//     buffer: 32 couts = 64-byte half lines, 2 stores per row, 8 per full tile -- the count the top-of-stage
+//     `s_waitcnt vmcnt(8)` lets stay in flight (checked in the listing at build time, Makefile / check_asm.py).
+// LDS map (bytes): [0, 40K) tile 0 | [40K, 76K) weights 0 | [80K, 120K) tile 1 | [120K, 156K) weights 1 | [156K, +256) bias.
+#include "conv_common.h"
+
+using convk::ConvParams;
+
+namespace {
+
+constexpr int TH11 = 16, TW11 = 32, NT11 = 4, NW11 = 8, CK11 = 32, NTHR11 = 512;
+constexpr int TIW11 = TW11 + 2, TIH11 = TH11 + 2, NPIX11 = TIW11 * TIH11;   // 34 x 18 = 612 halo pixels
+constexpr int TPIECES11 = (NPIX11 + 15) / 16;                               // 39 tile pieces of 16 pixels x 64 B
+constexpr int WPIECES11 = 2 * 18;                                           // 36 weight pieces (cout tile, k-step)
+constexpr int PIECES11 = TPIECES11 + WPIECES11;                             // 75 per stage
+constexpr int DMA11 = (PIECES11 + NW11 - 1) / NW11;                         // 10 slots per wave
+constexpr int TILE0_11 = 0, W0_11 = 40 * 1024, BUFSTEP11 = 80 * 1024, MISC11 = 156 * 1024;
+constexpr int LDS11 = MISC11 + 256;
+constexpr int EPS11 = 80, EROW11 = 32 * EPS11;                              // transposed half-line rows (32 px x 64 B + pad)
+static_assert(TPIECES11 * 1024 <= W0_11 && W0_11 + WPIECES11 * 1024 <= BUFSTEP11, "stage buffer layout");
+static_assert(NW11 * 2 * EROW11 <= W0_11, "epilogue scratch aliases a tile buffer");
+
+struct V11Extra {
+  int ntiles;
+  const half_t* zeros;      // >= 16 bytes of zeros: the DMA source of out-of-image halo pixels
+};
+
+__device__ __forceinline__ void glds16_11(const half_t* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void raw_barrier11() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(NTHR11, 1) void conv_mfma_v11_kernel(const ConvParams p, const V11Extra e) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  float* bias_s = reinterpret_cast<float*>(smem + MISC11);   // 64 floats
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mt = wave >> 2, rg = wave & 3;                   // cout tile (32 channels), row group (4 rows)
+  const int hh = lane >> 5, r = lane & 31;
+  const int cb = blockIdx.y, n = blockIdx.z;
+  const int nchunks = p.nchunks;
+
+  int first, stride, my_tiles;                               // XCD-aware: one contiguous band of tiles per L2
+  convk::xcd_tile_walk(e.ntiles, first, stride, my_tiles);
+  const int nstages = my_tiles * nchunks;
+  if (nstages <= 0) return;
+
+  // ---- per-lane DMA geometry.  Slot j of this wave is piece u = j * 8 + wave: u < 39 a tile piece (halo pixels 16u ..
+  // 16u + 15; this lane moves 16-byte slot (lane & 3) of pixel 16u + (lane >> 2), logical chunk slot ^ ((q >> 2) & 3)),
+  // 39 <= u < 75 weight piece u - 39 = cout tile * 18 + k-step (lane-linear: the fragment as it is read), u >= 75 nothing.
+  const int csw = (lane & 3) ^ ((lane >> 4) & 3);
+  int it_off[5];                                             // tile slots are j = 0 .. 4
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int q = 16 * (j * NW11 + wave) + (lane >> 2);
+    const int rr = q / TIW11, cc = q - rr * TIW11;
+    it_off[j] = q < NPIX11 ? (rr * p.W + cc) * p.x_sp + csw * 8 : csw * 8;
+  }
+  const half_t* xn = p.x + (long)n * p.x_sn;
+  const half_t* wcb = p.w + (long)cb * 2 * nchunks * 18 * 512 + lane * 8;     // + ((mt * nchunks + ch) * 18 + step) * 512
+
+  int pf_iy0 = 0, pf_ix0 = 0, pf_ch = 0;
+  bool pf_interior = false;
+  const half_t* pf_base = xn;
+  auto issue_prep = [&](int S) {
+    const int tile_i = S / nchunks, ch = S - tile_i * nchunks;
+    const int tile = p.reverse ? e.ntiles - 1 - (first + tile_i * stride) : first + tile_i * stride;
+    const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    pf_iy0 = ty * TH11 - 1;
+    pf_ix0 = tx * TW11 - 1;
+    pf_ch = ch;
+    pf_interior = pf_iy0 >= 0 && pf_ix0 >= 0 && pf_iy0 + TIH11 <= p.H && pf_ix0 + TIW11 <= p.W;
+    pf_base = xn + ((long)pf_iy0 * p.W + pf_ix0) * p.x_sp + ch * CK11;    // only dereferenced when interior
+  };
+  auto issue_one = [&](int j, unsigned dst_buf) {            // j is a compile-time constant at every call site
+    const int u = j * NW11 + wave;                           // wave-uniform
+    if (u < TPIECES11) {
+      if (j < 5) {
+        const half_t* src = pf_base + it_off[j < 5 ? j : 0];
+        if (!pf_interior) {              // uniform branch: border tiles clamp per lane
+          const int q = 16 * u + (lane >> 2);
+          const int rr = q / TIW11;
+          const int iy = pf_iy0 + rr, ix = pf_ix0 + (q - rr * TIW11);
+          const bool ok = q < NPIX11 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+          src = ok ? xn + ((long)iy * p.W + ix) * p.x_sp + pf_ch * CK11 + csw * 8 : e.zeros;
+        }
+        glds16_11(src, dst_buf + TILE0_11 + u * 1024);
+      }
+    } else if (u < PIECES11) {
+      const int v = u - TPIECES11;                           // cout tile v / 18, k-step v % 18
+      const int wm = v / 18, st = v - wm * 18;
+      glds16_11(wcb + ((long)(wm * nchunks + pf_ch) * 18 + st) * 512, dst_buf + W0_11 + v * 1024);
+    }
+  };
+
+  // ---- prologue: first stage's DMA, then the bias (a compiler-tracked load, younger than the DMA)
+  issue_prep(0);
+#pragma unroll
+  for (int j = 0; j < DMA11; ++j) issue_one(j, lds0);
+  if (tid < 64) bias_s[tid] = p.bias[cb * 64 + tid];
+
+  // ---- B-fragment read offsets (tile buffer 0, s2 = 0): input row ir of this wave's row group, column r + dx, chunk slot hh
+  int bq[NT11 + 2][3];
+#pragma unroll
+  for (int ir = 0; ir < NT11 + 2; ++ir)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int q = (rg * NT11 + ir) * TIW11 + r + dx;
+      bq[ir][dx] = TILE0_11 + q * 64 + ((hh ^ ((q >> 2) & 3)) << 4);
+    }
+  const int aoff = W0_11 + mt * 18 * 1024 + lane * 16;       // + (tap * 2 + s2) * 1024
+
+  __syncthreads();                       // bias visible (no DMA-aware wait here: see top of stage)
+  f32x16 bias16;                         // the C operand of every accumulator chain's first MFMA
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + mt * 32 + 8 * g + hh * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bias16[4 * g + i] = b4[i];
+  }
+
+  f32x16 acc[NT11];
+  bool stores_in_flight = false;         // the previous stage ended with exactly 8 epilogue stores (full tile)
+  for (int S = 0; S < nstages; ++S) {
+    const int tile_i = S / nchunks, ch = S - tile_i * nchunks;
+    const unsigned bofs = (S & 1) ? BUFSTEP11 : 0;
+    // This wave's DMA pieces of stage S have landed: they are older than the (at most 8) epilogue stores.
+    if (stores_in_flight) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    raw_barrier11();                     // every wave's pieces landed; every wave is done with the other buffer
+    const bool have_next = S + 1 < nstages;
+    if (have_next) issue_prep(S + 1);
+    const unsigned nbuf = lds0 + (bofs ^ BUFSTEP11);
+    const unsigned char* sb = smem + bofs;
+
+    // matrix phase: 6 groups (s2, dx) of 12 MFMAs; group g+1's 9 fragment reads are issued under group g's MFMAs
+    half8 fa[2][3], fb[2][NT11 + 2];
+    auto load_group = [&](int g, int buf) {
+      const int s2 = g / 3, dx = g - 3 * s2;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) fa[buf][dy] = *reinterpret_cast<const half8*>(sb + aoff + ((dy * 3 + dx) * 2 + s2) * 1024);
+#pragma unroll
+      for (int ir = 0; ir < NT11 + 2; ++ir) fb[buf][ir] = *reinterpret_cast<const half8*>(sb + (bq[ir][dx] ^ (s2 * 32)));
+    };
+    load_group(0, 0);
+    __builtin_amdgcn_sched_barrier(0);   // group 0's own reads go out back to back
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+      if (g + 1 < 6) load_group(g + 1, (g + 1) & 1);
+#pragma unroll
+      for (int ir = 0; ir < NT11 + 2; ++ir)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int nt = ir - dy;
+          if (nt >= 0 && nt < NT11) {
+            const bool first_of_chain = g == 0 && dy == 0;   // and ch == 0 (run time): the chain of acc[nt] starts here
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][dy], fb[g & 1][ir], (first_of_chain && ch == 0) ? bias16 : acc[nt], 0, 0, 0);
+          }
+        }
+      if (g + 1 < 6) {                   // pin the software pipeline: the next group's 9 reads between this group's MFMAs
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+      }
+      if (have_next && g < 5) {          // 10 DMA slots of the next stage, two per group
+        issue_one(2 * g, nbuf);
+        issue_one(2 * g + 1, nbuf);
+      }
+    }
+    stores_in_flight = false;
+    if (ch != nchunks - 1) continue;
+
+    // ---- epilogue: 32 couts x 4 rows of this wave, transposed through the finished tile buffer
+    const int tile = p.reverse ? e.ntiles - 1 - (first + tile_i * stride) : first + tile_i * stride;
+    const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    const bool full = (ty + 1) * TH11 <= p.Ho && (tx + 1) * TW11 <= p.Wo;
+    raw_barrier11();                     // all waves finished reading this stage's buffers: the tile buffer becomes scratch
+    {
+      unsigned char* ew = smem + bofs + TILE0_11 + wave * (2 * EROW11);
+      const int chunk = lane & 3, prow = lane >> 2;          // 8 channels (16 B) of pixel prow (+16 for the second pass)
+      const int co = cb * 64 + mt * 32 + chunk * 8;
+      const bool ch_ok = co < p.y.C && co < ((p.cout + 63) & ~63);
+      const int cc = ch_ok ? co : 0;
+      const int oy0 = ty * TH11 + rg * NT11, ox0 = tx * TW11;
+      const bool has1 = p.res.p != nullptr, has2 = p.res2.p != nullptr;    // wave-uniform
+      const half_t sl = (half_t)p.slope;
+      const half2v sl2 = {sl, sl}, zero2 = {(half_t)0.f, (half_t)0.f};
+      const bool act = p.slope != 1.f, relu = p.slope == 0.f;
+      half_t* yb = reinterpret_cast<half_t*>(p.y.p) + (long)n * p.y.sn + cc;
+      const half_t* rb1 = reinterpret_cast<const half_t*>(p.res.p) + (long)n * p.res.sn + cc;
+      const half_t* rb2 = reinterpret_cast<const half_t*>(p.res2.p) + (long)n * p.res2.sn + cc;
+#pragma unroll
+      for (int j = 0; j < NT11; ++j) {
+        int opix[2];
+        bool ok[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int ox = ox0 + k * 16 + prow;
+          ok[k] = full ? ch_ok : (ch_ok && oy0 + j < p.Ho && ox < p.Wo);
+          opix[k] = ok[k] ? (oy0 + j) * p.Wo + ox : 0;
+        }
+        half8 r1[2], r2[2];
+        if (has1) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) r1[k] = *reinterpret_cast<const half8*>(rb1 + (long)opix[k] * p.res.sp);
+        }
+        if (has2) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) r2[k] = *reinterpret_cast<const half8*>(rb2 + (long)opix[k] * p.res2.sp);
+        }
+        unsigned char* er = ew + (j & 1) * EROW11;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          half2v lo = {(half_t)acc[j][4 * g + 0], (half_t)acc[j][4 * g + 1]};
+          half2v hi = {(half_t)acc[j][4 * g + 2], (half_t)acc[j][4 * g + 3]};
+          if (relu) {
+            lo = __builtin_elementwise_max(lo, zero2);
+            hi = __builtin_elementwise_max(hi, zero2);
+          } else if (act) {
+            lo = __builtin_elementwise_max(lo, lo * sl2);
+            hi = __builtin_elementwise_max(hi, hi * sl2);
+          }
+          const half4 o = {lo[0], lo[1], hi[0], hi[1]};
+          *reinterpret_cast<half4*>(er + r * EPS11 + (8 * g + 4 * hh) * 2) = o;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          half8 v = *reinterpret_cast<const half8*>(er + (k * 16 + prow) * EPS11 + chunk * 16);
+          if (has1) v = v + r1[k];
+          if (has2) v = v + r2[k];
+          if (ok[k]) *reinterpret_cast<half8*>(yb + (long)opix[k] * p.y.sp) = v;
+        }
+      }
+    }
+    stores_in_flight = full;
+  }
+}
+
+}  // namespace
+
+static bool g_v11_enabled = true;
+// tests and A/B benchmarks switch the kernel off to send the same layers to conv_mfma_v3
+extern "C" void tdvc_debug_enable_conv_v11(int enable) { g_v11_enabled = enable != 0; }
+
+bool conv_v11_eligible(const tdvc_conv_desc* d, const ConvParams& p, int Ho, int Wo) {
+  static const bool off = getenv("TDVC_CONV_NO_V11") != nullptr || getenv("TDVC_CONV_V1") != nullptr;
+  static const int min_cin = getenv("TDVC_V11_MIN_CIN") ? atoi(getenv("TDVC_V11_MIN_CIN")) : 128;
+  if (off || !g_v11_enabled) return false;
+  bool taps33 = d->ntaps == 9 && d->kh == 3 && d->kw == 3 && d->pad == 1;
+  for (int t = 0; taps33 && t < 9; ++t) taps33 = d->tap_dy[t] == t / 3 && d->tap_dx[t] == t % 3;
+  return taps33 && d->ck == 32 && d->stride == 1 && d->cout >= 64 && (d->cout % 64) == 0 && (d->x.C % 32) == 0 && d->x.C >= min_cin && !d->s2d &&
+         !d->square_input && (long)Ho * Wo >= 8192 && convk::conv_is_lean(p);
+}
+
+int launch_conv_v11(const ConvParams& p, int cout_blocks, int N, hipStream_t st) {
+  static half_t* zeros = nullptr;
+  if (!zeros) {
+    hipError_t err = hipMalloc(reinterpret_cast<void**>(&zeros), 256);
+    if (err == hipSuccess) err = hipMemset(zeros, 0, 256);
+    if (err != hipSuccess) { zeros = nullptr; tdvc_set_error("conv v11: zero page allocation failed: %s", hipGetErrorString(err)); return (int)err; }
+  }
+  ConvParams q = p;
+  q.tiles_x = (p.Wo + TW11 - 1) / TW11;
+  const int tiles_y = (p.Ho + TH11 - 1) / TH11;
+  V11Extra e;
+  e.ntiles = q.tiles_x * tiles_y;
+  e.zeros = zeros;
+  q.slope = convk::conv_simple_slope(p);
+  int gx = 256 / (cout_blocks * N);
+  if (gx < 1) gx = 1;
+  if (gx > e.ntiles) gx = e.ntiles;
+  dim3 grid(gx, cout_blocks, N);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v11_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (err != hipSuccess) { tdvc_set_error("conv v11: hipFuncSetAttribute failed: %s", hipGetErrorString(err)); return (int)err; }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(conv_mfma_v11_kernel, grid, dim3(NTHR11), LDS11, st, q, e);
+  return tdvc_launch_status("tdvc_conv2d(v11)");
+}

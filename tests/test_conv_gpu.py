@@ -383,3 +383,32 @@ def test_conv_1x1_stride2_large(cin, cout, H, W, report):
     assert pc.ck == 32
     y = ops.conv(to_fm(x, ops), pc)
     assert_close(fm_to_cpu(y), F.conv2d(x, w, b, stride=2), RT, AT, f"1x1 s2 {cin}->{cout} {H}x{W}", report)
+
+
+# ---- 3x3 stride-1 convs with Cin >= 128 (weights streamed per stage by LDS-DMA: conv_mfma_v11; v3 with it switched off)
+V11_CASES = [
+    # name, N, cin, cout, H, W, act, n_res
+    ("v11_128_128_ragged", 1, 128, 128, 100, 150, "lrelu", 1),       # partial tiles on both edges, 4 stages per tile
+    ("v11_128_64_exact", 1, 128, 64, 96, 128, "relu", 0),            # every tile full (counted-store path)
+    ("v11_128_128_batch2", 2, 128, 128, 90, 120, "lrelu", 2),        # batch in grid.z, two residuals
+    ("v11_192_64", 1, 192, 64, 96, 100, "none", 0),                  # 6 stages per tile
+    ("v11_128_128_many_tiles", 1, 128, 128, 272, 480, "lrelu", 1),   # several tiles per persistent workgroup
+    ("v11_256_64_narrow", 1, 256, 64, 300, 40, "none", 1),           # 8 stages, 2 tile columns
+]
+
+
+@pytest.mark.parametrize("v11", [True, False], ids=["v11", "v3"])
+@pytest.mark.parametrize("case", V11_CASES, ids=[c[0] for c in V11_CASES])
+def test_conv_v11(case, v11, report):
+    import ctypes
+
+    from tdvc_amd import _lib
+    ops = _ops()
+    name, N, cin, cout, H, W, act, n_res = case
+    fn = _lib.lib().tdvc_debug_enable_conv_v11
+    fn.argtypes, fn.restype = [ctypes.c_int], None
+    fn(1 if v11 else 0)
+    try:
+        _run_conv_dma_case(ops, name, N, cin, cout, H, W, act, n_res, "conv_mfma_v11" if v11 else "conv_mfma_v3", report)
+    finally:
+        fn(1)

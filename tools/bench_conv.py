@@ -33,8 +33,11 @@ LAYERS = [
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="", help="substring filter on the layer names")
     a = ap.parse_args()
     for name, cin, cout, k, s, H, W in LAYERS:
+        if a.only and a.only not in name:
+            continue
         zero = os.environ.get("TDVC_BENCH_ZERO") == "1"      # zero operands: separates power-limited clocks from stalls
         x = ops.FM((torch.zeros if zero else torch.randn)(1, H, W, cin, device="cuda").half())
         w = (torch.zeros if zero else torch.randn)(cout, cin, k, k) * 0.05
@@ -51,7 +54,10 @@ def main():
         Ho, Wo = y.H, y.W
         fl = 2.0 * Ho * Wo * cout * cin * k * k
         by = 2.0 * (H * W * cin + Ho * Wo * cout)
-        print(f"{name:32s} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s  {by/ms/1e6:8.1f} GB/s (algorithmic)  ck={pc.ck}", flush=True)
+        kern = ops.L.lib().tdvc_last_conv_kernel().decode()
+        print(f"{name:32s} {kern:16s} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s  {by/ms/1e6:8.1f} GB/s (algorithmic)  ck={pc.ck}", flush=True)
+    if a.only:
+        return
     # fused DCN at 1080p
     from tdvc_amd.model.modules import DCN
     m = DCN(64, 64, 3, 1, 1, deformable_groups=8).cuda()
