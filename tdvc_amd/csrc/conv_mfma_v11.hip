@@ -1,6 +1,6 @@
 // conv_mfma_v11 — 3x3, stride 1, pad 1, Cin a multiple of 32 with Cin >= 128 (the 128->128 / 128->64 convs of the coders, MCNet
 // and the in-loop filter: 7.7 ms per 1080p frame on conv_mfma_v3 at 0.27-0.29 of the MFMA peak), Cout >= 64, lean epilogue
-// (fp16 NHWC, no GDN / PixelShuffle).
+// (fp16 NHWC or PixelShuffle(2) store, no GDN).
 //
 // These layers are compute-bound (575 FLOP/B at 128->128) but cannot be weight-stationary: 64 couts x 128 cin x 9 taps is
 // 144 KB.  v3 stages tile AND weights of every 32-channel stage global -> VGPR -> LDS (measured: 4.3 k cycles of load-issue
@@ -203,8 +203,17 @@ __global__ __launch_bounds__(NTHR11, 1) void conv_mfma_v11_kernel(const ConvPara
       unsigned char* ew = smem + bofs + TILE0_11 + wave * (2 * EROW11);
       const int chunk = lane & 3, prow = lane >> 2;          // 8 channels (16 B) of pixel prow (+16 for the second pass)
       const int co = cb * 64 + mt * 32 + chunk * 8;
-      const bool ch_ok = co < p.y.C && co < ((p.cout + 63) & ~63);
-      const int cc = ch_ok ? co : 0;
+      // PixelShuffle(2) store (sub-pixel convs): the host packs the rows as (i*2+j)*cq + c, so a 32-row tile of this wave
+      // lies inside one sub-pixel (cq % 32 == 0, eligibility): output pixel (2 oy + i, 2 ox + j), channels pc ..
+      int pc = co, sub_y = 0, sub_x = 0, mul = 1, PW = p.Wo;
+      if (p.out_mode == TDVC_OUT_SHUFFLE2) {
+        const int cq = p.cout >> 2;
+        const int sub = co / cq;
+        pc = co - sub * cq;
+        sub_y = sub >> 1; sub_x = sub & 1; mul = 2; PW = 2 * p.Wo;
+      }
+      const bool ch_ok = pc < p.y.C && co < ((p.cout + 63) & ~63);
+      const int cc = ch_ok ? pc : 0;
       const int oy0 = ty * TH11 + rg * NT11, ox0 = tx * TW11;
       const bool has1 = p.res.p != nullptr, has2 = p.res2.p != nullptr;    // wave-uniform
       const half_t sl = (half_t)p.slope;
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(NTHR11, 1) void conv_mfma_v11_kernel(const ConvPara
         for (int k = 0; k < 2; ++k) {
           const int ox = ox0 + k * 16 + prow;
           ok[k] = full ? ch_ok : (ch_ok && oy0 + j < p.Ho && ox < p.Wo);
-          opix[k] = ok[k] ? (oy0 + j) * p.Wo + ox : 0;
+          opix[k] = ok[k] ? (mul * (oy0 + j) + sub_y) * PW + mul * ox + sub_x : 0;
         }
         half8 r1[2], r2[2];
         if (has1) {
@@ -273,7 +282,8 @@ bool conv_v11_eligible(const tdvc_conv_desc* d, const ConvParams& p, int Ho, int
   bool taps33 = d->ntaps == 9 && d->kh == 3 && d->kw == 3 && d->pad == 1;
   for (int t = 0; taps33 && t < 9; ++t) taps33 = d->tap_dy[t] == t / 3 && d->tap_dx[t] == t % 3;
   return taps33 && d->ck == 32 && d->stride == 1 && d->cout >= 64 && (d->cout % 64) == 0 && (d->x.C % 32) == 0 && d->x.C >= min_cin && !d->s2d &&
-         !d->square_input && (long)Ho * Wo >= 8192 && convk::conv_is_lean(p);
+         !d->square_input && (long)Ho * Wo >= 8192 &&
+         (convk::conv_is_lean(p) || (convk::conv_is_simple(p) && !p.gdn && p.out_mode == TDVC_OUT_SHUFFLE2 && ((d->cout >> 2) % 32) == 0));
 }
 
 int launch_conv_v11(const ConvParams& p, int cout_blocks, int N, hipStream_t st) {

@@ -412,3 +412,41 @@ def test_conv_v11(case, v11, report):
         _run_conv_dma_case(ops, name, N, cin, cout, H, W, act, n_res, "conv_mfma_v11" if v11 else "conv_mfma_v3", report)
     finally:
         fn(1)
+
+
+@pytest.mark.parametrize("v11", [True, False], ids=["v11", "v3"])
+@pytest.mark.parametrize("cout,H,W,nres", [(128, 96, 128, 1), (64, 100, 150, 0), (128, 90, 120, 2)])
+def test_conv_v11_pixel_shuffle(cout, H, W, nres, v11, report):
+    """sub-pixel convs 128 -> 4 * cout with the PixelShuffle(2) store (the coders' ResidualBlockUpsample and final g_s layers)"""
+    import ctypes
+
+    from tdvc_amd import _lib
+    ops = _ops()
+    fn = _lib.lib().tdvc_debug_enable_conv_v11
+    fn.argtypes, fn.restype = [ctypes.c_int], None
+    fn(1 if v11 else 0)
+    try:
+        x = rnd16(randn(1, 128, H, W, seed=91))
+        w = rnd16(randn(4 * cout, 128, 3, 3, seed=92) * 0.03)
+        b = randn(4 * cout, seed=93) * 0.1
+        rs = [rnd16(randn(1, cout, 2 * H, 2 * W, seed=94 + i)) for i in range(nres)]
+        ref = F.leaky_relu(F.pixel_shuffle(F.conv2d(x, w, b, padding=1), 2), 0.01)
+        for r_ in rs:
+            ref = ref + r_
+        kw = dict(act=ops.ACT_LRELU, slope=0.01)
+        if nres > 0:
+            kw["res"] = to_fm(rs[0], ops)
+        if nres > 1:
+            kw["res2"] = to_fm(rs[1], ops)
+        xf = to_fm(x, ops)
+        pc = ops.pack_conv(w, b, stride=1, pad=1, shuffle=True)
+        y = ops.conv(xf, pc, **kw)
+        kern = ops.L.lib().tdvc_last_conv_kernel().decode()
+        assert kern == ("conv_mfma_v11" if v11 else "conv_mfma_v3"), kern
+        assert_close(fm_to_cpu(y), ref, RT, AT, f"subpel 128->{cout} @{H}x{W} on {kern}", report)
+        first = y.t.clone()
+        for _ in range(4):
+            ops.conv(xf, pc, out=y, **kw)
+            assert torch.equal(y.t, first), "launch-to-launch mismatch"
+    finally:
+        fn(1)
