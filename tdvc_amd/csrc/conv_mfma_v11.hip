@@ -8,11 +8,11 @@
 //   * a stage = one 32-channel chunk of a 16x32-px tile (39 KB halo image, XOR-swizzled as in v7) + the 64-cout weight
 //     slice of that chunk (36 KB = 2 cout tiles x 18 k-steps x 1 KB, already in MFMA fragment order in global memory, so
 //     a DMA piece IS a fragment); two stage buffers (2 x 76 KB); stage S+1 streams in during stage S's matrix phase:
-//     75 pieces over 8 waves, hidden behind the partner wave of each SIMD;
+//     75 pieces, waves 0-3 the tile, waves 4-7 the weights (affine slot addressing), hidden behind the partner wave of each SIMD;
 //   * 8 waves = 2 cout tiles x 4 row groups; a wave computes 32 couts x (4 rows x 32 px): four accumulators, and for a
 //     fixed (k-half, dx) the B fragment of input row ir serves output rows ir, ir-1, ir-2: 3 A + 6 B reads per 12 MFMAs
 //     (0.75 LDS reads per MFMA; v3 / v7: 1.0);
-//   * bias as the C operand of each accumulator chain's first MFMA; lean packed-fp16 epilogue through the finished tile
+//   * accumulators start from the bias; lean packed-fp16 epilogue through the finished tile
 //     buffer: 32 couts = 64-byte half lines, 2 stores per row, 8 per full tile -- the count the top-of-stage
 //     `s_waitcnt vmcnt(8)` lets stay in flight (checked in the listing at build time, Makefile / check_asm.py).
 // LDS map (bytes): [0, 40K) tile 0 | [40K, 76K) weights 0 | [80K, 120K) tile 1 | [120K, 156K) weights 1 | [156K, +256) bias.
@@ -36,6 +36,7 @@ static_assert(NW11 * 2 * EROW11 <= W0_11, "epilogue scratch aliases a tile buffe
 
 struct V11Extra {
   int ntiles;
+  int experiment;           // 0 in every product launch (see g_v11_experiment)
   const half_t* zeros;      // >= 16 bytes of zeros: the DMA source of out-of-image halo pixels
 };
 
@@ -50,7 +51,16 @@ __device__ __forceinline__ void raw_barrier11() {
   asm volatile("" ::: "memory");
 }
 
-__global__ __launch_bounds__(NTHR11, 1) void conv_mfma_v11_kernel(const ConvParams p, const V11Extra e) {
+static long long* g_stamp11 = nullptr;
+static int g_stamp11_cap = 0;
+static int g_v11_experiment = 0;     // diagnostic builds only (wrong results): 1 = no weight DMA, 2 = no DMA at all, 3 = one fragment read per group
+
+template <bool STAMP = false>
+__global__ __launch_bounds__(NTHR11, 1) void conv_mfma_v11_kernel(const ConvParams p, const V11Extra e, long long* stamps = nullptr, int stamp_cap = 0) {
+  long long stv[16];
+  if constexpr (STAMP) { for (int i = 0; i < 16; ++i) stv[i] = 0; }
+  // instrumented: the LAST stage of the workgroup's second tile (stamps 0..5) and the stage before it (stamps 8..11)
+#define ST11(i) do { if constexpr (STAMP) { if (S == 2 * nchunks - 1) stv[i] = clock64(); else if (S == 2 * nchunks - 2 && (i) < 4) stv[8 + (i)] = clock64(); } } while (0)
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   float* bias_s = reinterpret_cast<float*>(smem + MISC11);   // 64 floats
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
@@ -67,51 +77,57 @@ __global__ __launch_bounds__(NTHR11, 1) void conv_mfma_v11_kernel(const ConvPara
   const int nstages = my_tiles * nchunks;
   if (nstages <= 0) return;
 
-  // ---- per-lane DMA geometry.  Slot j of this wave is piece u = j * 8 + wave: u < 39 a tile piece (halo pixels 16u ..
-  // 16u + 15; this lane moves 16-byte slot (lane & 3) of pixel 16u + (lane >> 2), logical chunk slot ^ ((q >> 2) & 3)),
-  // 39 <= u < 75 weight piece u - 39 = cout tile * 18 + k-step (lane-linear: the fragment as it is read), u >= 75 nothing.
+  // ---- DMA roles.  Waves 0-3 move the TILE: slot j of wave w is piece u = j * 4 + w (10 slots, u < 39): halo pixels 16u ..
+  // 16u + 15; this lane moves 16-byte slot (lane & 3) of pixel 16u + (lane >> 2), logical chunk slot ^ ((q >> 2) & 3).
+  // Waves 4-7 move the WEIGHTS: slot j of wave 4 + w is fragment (cout tile w & 1, k-step 2j + (w >> 1)), 9 slots: source and
+  // destination are affine in j with wave-constant bases (a piece is lane-linear: the fragment as it is read), so a slot
+  // costs one 64-bit add and the M0 write -- the mixed assignment of the first version spent ~35 scalar instructions and
+  // 5 v_readlane (spilled SGPRs) per slot.
+  const bool tile_role = wave < 4;                           // wave-uniform
+  const int w3 = wave & 3;
   const int csw = (lane & 3) ^ ((lane >> 4) & 3);
-  int it_off[5];                                             // tile slots are j = 0 .. 4
-#pragma unroll
-  for (int j = 0; j < 5; ++j) {
-    const int q = 16 * (j * NW11 + wave) + (lane >> 2);
-    const int rr = q / TIW11, cc = q - rr * TIW11;
-    it_off[j] = q < NPIX11 ? (rr * p.W + cc) * p.x_sp + csw * 8 : csw * 8;
-  }
+  const int q0 = 16 * w3 + (lane >> 2);                      // halo pixel of this lane in slot 0; slot j: + 64 j
+  const int xrow = p.W * p.x_sp;                             // elements per image row (the per-lane slot offsets are recomputed per
+                                                             // slot: ten of them in registers spilled the 256-VGPR budget)
   const half_t* xn = p.x + (long)n * p.x_sn;
-  const half_t* wcb = p.w + (long)cb * 2 * nchunks * 18 * 512 + lane * 8;     // + ((mt * nchunks + ch) * 18 + step) * 512
+  // weights of cout block cb: [cout tile 2][chunk][k-step 18][lane 64][8]; this wave's fragment column
+  const half_t* wsrc0 = p.w + ((long)(cb * 2 + (w3 & 1)) * nchunks * 18 + (w3 >> 1)) * 512 + lane * 8;    // + (ch * 18 + 2j) * 512
+  const unsigned wdst0 = W0_11 + ((w3 & 1) * 18 + (w3 >> 1)) * 1024;                                       // + 2j * 1024
 
   int pf_iy0 = 0, pf_ix0 = 0, pf_ch = 0;
   bool pf_interior = false;
   const half_t* pf_base = xn;
+  const half_t* pf_w = wsrc0;
   auto issue_prep = [&](int S) {
     const int tile_i = S / nchunks, ch = S - tile_i * nchunks;
-    const int tile = p.reverse ? e.ntiles - 1 - (first + tile_i * stride) : first + tile_i * stride;
-    const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-    pf_iy0 = ty * TH11 - 1;
-    pf_ix0 = tx * TW11 - 1;
     pf_ch = ch;
-    pf_interior = pf_iy0 >= 0 && pf_ix0 >= 0 && pf_iy0 + TIH11 <= p.H && pf_ix0 + TIW11 <= p.W;
-    pf_base = xn + ((long)pf_iy0 * p.W + pf_ix0) * p.x_sp + ch * CK11;    // only dereferenced when interior
+    pf_w = wsrc0 + (long)ch * 18 * 512;
+    if (tile_role) {
+      const int tile = p.reverse ? e.ntiles - 1 - (first + tile_i * stride) : first + tile_i * stride;
+      const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+      pf_iy0 = ty * TH11 - 1;
+      pf_ix0 = tx * TW11 - 1;
+      pf_interior = pf_iy0 >= 0 && pf_ix0 >= 0 && pf_iy0 + TIH11 <= p.H && pf_ix0 + TIW11 <= p.W;
+      pf_base = xn + ((long)pf_iy0 * p.W + pf_ix0) * p.x_sp + ch * CK11;  // only dereferenced when interior
+    }
   };
   auto issue_one = [&](int j, unsigned dst_buf) {            // j is a compile-time constant at every call site
-    const int u = j * NW11 + wave;                           // wave-uniform
-    if (u < TPIECES11) {
-      if (j < 5) {
-        const half_t* src = pf_base + it_off[j < 5 ? j : 0];
+    if constexpr (STAMP) { if (e.experiment == 2 || (e.experiment == 1 && !tile_role)) return; }
+    if (tile_role) {
+      const int u = j * 4 + w3;
+      if (u < TPIECES11) {
+        const int q = q0 + 64 * j;
+        const int rr = q / TIW11, cc = q - rr * TIW11;
+        const half_t* src = pf_base + (q < NPIX11 ? rr * xrow + cc * p.x_sp : 0) + csw * 8;
         if (!pf_interior) {              // uniform branch: border tiles clamp per lane
-          const int q = 16 * u + (lane >> 2);
-          const int rr = q / TIW11;
-          const int iy = pf_iy0 + rr, ix = pf_ix0 + (q - rr * TIW11);
+          const int iy = pf_iy0 + rr, ix = pf_ix0 + cc;
           const bool ok = q < NPIX11 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
           src = ok ? xn + ((long)iy * p.W + ix) * p.x_sp + pf_ch * CK11 + csw * 8 : e.zeros;
         }
         glds16_11(src, dst_buf + TILE0_11 + u * 1024);
       }
-    } else if (u < PIECES11) {
-      const int v = u - TPIECES11;                           // cout tile v / 18, k-step v % 18
-      const int wm = v / 18, st = v - wm * 18;
-      glds16_11(wcb + ((long)(wm * nchunks + pf_ch) * 18 + st) * 512, dst_buf + W0_11 + v * 1024);
+    } else if (j < 9) {
+      glds16_11(pf_w + j * 1024, dst_buf + wdst0 + j * 2048);
     }
   };
 
@@ -133,32 +149,48 @@ __global__ __launch_bounds__(NTHR11, 1) void conv_mfma_v11_kernel(const ConvPara
   const int aoff = W0_11 + mt * 18 * 1024 + lane * 16;       // + (tap * 2 + s2) * 1024
 
   __syncthreads();                       // bias visible (no DMA-aware wait here: see top of stage)
-  f32x16 bias16;                         // the C operand of every accumulator chain's first MFMA
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + mt * 32 + 8 * g + hh * 4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bias16[4 * g + i] = b4[i];
-  }
-
   f32x16 acc[NT11];
   bool stores_in_flight = false;         // the previous stage ended with exactly 8 epilogue stores (full tile)
   for (int S = 0; S < nstages; ++S) {
     const int tile_i = S / nchunks, ch = S - tile_i * nchunks;
     const unsigned bofs = (S & 1) ? BUFSTEP11 : 0;
     // This wave's DMA pieces of stage S have landed: they are older than the (at most 8) epilogue stores.
+    ST11(0);
     if (stores_in_flight) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ST11(1);
     raw_barrier11();                     // every wave's pieces landed; every wave is done with the other buffer
+    ST11(2);
     const bool have_next = S + 1 < nstages;
     if (have_next) issue_prep(S + 1);
     const unsigned nbuf = lds0 + (bofs ^ BUFSTEP11);
     const unsigned char* sb = smem + bofs;
 
+    if (ch == 0) {                       // a new tile: the four accumulators start from the bias, re-read from LDS (a bias vector
+      f32x16 b16;                        // kept in 16 registers for the whole launch spilled the 256-VGPR budget; a per-MFMA
+#pragma unroll                           // select between bias and accumulator cost 190 v_cndmask per STAGE)
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + mt * 32 + 8 * g + hh * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b16[4 * g + i] = b4[i];
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT11; ++nt) acc[nt] = b16;
+    }
     // matrix phase: 6 groups (s2, dx) of 12 MFMAs; group g+1's 9 fragment reads are issued under group g's MFMAs
     half8 fa[2][3], fb[2][NT11 + 2];
     auto load_group = [&](int g, int buf) {
       const int s2 = g / 3, dx = g - 3 * s2;
+      if constexpr (STAMP) {
+        if (e.experiment == 3) {         // diagnostic: a single LDS read per group, the other fragments alias it
+          const half8 v = *reinterpret_cast<const half8*>(sb + aoff + (dx * 2 + s2) * 1024);
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) fa[buf][dy] = v;
+#pragma unroll
+          for (int ir = 0; ir < NT11 + 2; ++ir) fb[buf][ir] = v;
+          return;
+        }
+      }
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) fa[buf][dy] = *reinterpret_cast<const half8*>(sb + aoff + ((dy * 3 + dx) * 2 + s2) * 1024);
 #pragma unroll
@@ -175,8 +207,7 @@ __global__ __launch_bounds__(NTHR11, 1) void conv_mfma_v11_kernel(const ConvPara
         for (int dy = 0; dy < 3; ++dy) {
           const int nt = ir - dy;
           if (nt >= 0 && nt < NT11) {
-            const bool first_of_chain = g == 0 && dy == 0;   // and ch == 0 (run time): the chain of acc[nt] starts here
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][dy], fb[g & 1][ir], (first_of_chain && ch == 0) ? bias16 : acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][dy], fb[g & 1][ir], acc[nt], 0, 0, 0);
           }
         }
       if (g + 1 < 6) {                   // pin the software pipeline: the next group's 9 reads between this group's MFMAs
@@ -191,6 +222,7 @@ __global__ __launch_bounds__(NTHR11, 1) void conv_mfma_v11_kernel(const ConvPara
         issue_one(2 * g + 1, nbuf);
       }
     }
+    ST11(3);
     stores_in_flight = false;
     if (ch != nchunks - 1) continue;
 
@@ -199,6 +231,7 @@ __global__ __launch_bounds__(NTHR11, 1) void conv_mfma_v11_kernel(const ConvPara
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     const bool full = (ty + 1) * TH11 <= p.Ho && (tx + 1) * TW11 <= p.Wo;
     raw_barrier11();                     // all waves finished reading this stage's buffers: the tile buffer becomes scratch
+    ST11(4);
     {
       unsigned char* ew = smem + bofs + TILE0_11 + wave * (2 * EROW11);
       const int chunk = lane & 3, prow = lane >> 2;          // 8 channels (16 B) of pixel prow (+16 for the second pass)
@@ -266,10 +299,20 @@ __global__ __launch_bounds__(NTHR11, 1) void conv_mfma_v11_kernel(const ConvPara
       }
     }
     stores_in_flight = full;
+    ST11(5);
+    if constexpr (STAMP) {
+      if (S == 2 * nchunks - 1 && lane == 0) {   // one record per wave: [block][wave][16 stamps]
+        const int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (bid * 8 + 7 < stamp_cap) for (int i = 0; i < 16; ++i) stamps[((long)bid * 8 + wave) * 16 + i] = stv[i];
+      }
+    }
   }
 }
 
 }  // namespace
+
+extern "C" void tdvc_debug_set_stamp_buffer_v11(void* buf, int cap_blocks) { g_stamp11 = (long long*)buf; g_stamp11_cap = cap_blocks; }
+extern "C" void tdvc_debug_set_v11_experiment(int mode) { g_v11_experiment = mode; }
 
 static bool g_v11_enabled = true;
 // tests and A/B benchmarks switch the kernel off to send the same layers to conv_mfma_v3
@@ -299,6 +342,7 @@ int launch_conv_v11(const ConvParams& p, int cout_blocks, int N, hipStream_t st)
   V11Extra e;
   e.ntiles = q.tiles_x * tiles_y;
   e.zeros = zeros;
+  e.experiment = g_v11_experiment;
   q.slope = convk::conv_simple_slope(p);
   int gx = 256 / (cout_blocks * N);
   if (gx < 1) gx = 1;
@@ -306,10 +350,13 @@ int launch_conv_v11(const ConvParams& p, int cout_blocks, int N, hipStream_t st)
   dim3 grid(gx, cout_blocks, N);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v11_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v11_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (err == hipSuccess)
+      err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v11_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err != hipSuccess) { tdvc_set_error("conv v11: hipFuncSetAttribute failed: %s", hipGetErrorString(err)); return (int)err; }
     attr_done = true;
   }
-  hipLaunchKernelGGL(conv_mfma_v11_kernel, grid, dim3(NTHR11), LDS11, st, q, e);
+  if (g_stamp11) hipLaunchKernelGGL(conv_mfma_v11_kernel<true>, grid, dim3(NTHR11), LDS11, st, q, e, g_stamp11, g_stamp11_cap);
+  else hipLaunchKernelGGL(conv_mfma_v11_kernel<false>, grid, dim3(NTHR11), LDS11, st, q, e, (long long*)nullptr, 0);
   return tdvc_launch_status("tdvc_conv2d(v11)");
 }

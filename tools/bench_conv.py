@@ -35,6 +35,11 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="", help="substring filter on the layer names")
     a = ap.parse_args()
+    if os.environ.get("V11_EXPERIMENT"):
+        import ctypes
+        ex = ops.L.lib().tdvc_debug_set_v11_experiment
+        ex.argtypes = [ctypes.c_int]
+        ex(int(os.environ["V11_EXPERIMENT"]))
     for name, cin, cout, k, s, H, W in LAYERS:
         if a.only and a.only not in name:
             continue
