@@ -24,6 +24,9 @@ struct ConvParams {
 // Epilogue for 4 consecutive output channels co..co+3 of output pixel (oy, ox) of image n:
 // bias -> GDN -> fp16 rounding (DCN quirk) -> activation -> residual(s) -> store (NHWC fp16 / fp32,
 // PixelShuffle(2), planar fp32).
+// F32MAPS: fp32 GDN multiplicand / fp32 second residual (only conv_f32 passes them; keeping the branches out of the fp16
+// kernels saves them 16 VGPRs: conv_mfma<4,1,1> 104 -> 88)
+template <bool F32MAPS = false>
 __device__ __forceinline__ void epilogue4(const ConvParams& p, int n, int oy, int ox, int co, float v[4]) {
   if (p.bias) {
     const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + co);
@@ -42,7 +45,7 @@ __device__ __forceinline__ void epilogue4(const ConvParams& p, int n, int oy, in
   }
   if (p.gdn) {
     float a[4];
-    if (p.aux.f32) {                       // fp32 islands (conv_f32): exact 1 / sqrtf like the reference's torch.rsqrt on CPU
+    if (F32MAPS && p.aux.f32) {            // fp32 islands (conv_f32): exact 1 / sqrtf like the reference's torch.rsqrt on CPU
       const f32x4 a4 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.aux.p) + (long)n * p.aux.sn + ((long)oy * p.Wo + ox) * p.aux.sp + co);
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = a4[i] * (p.gdn == TDVC_GDN_FWD ? 1.0f / sqrtf(v[i]) : sqrtf(v[i]));
@@ -76,7 +79,7 @@ __device__ __forceinline__ void epilogue4(const ConvParams& p, int n, int oy, in
     }
   }
   if (p.res2.p && pc < p.res2.C) {
-    if (p.res2.f32) {
+    if (F32MAPS && p.res2.f32) {
       const float* rp = reinterpret_cast<const float*>(p.res2.p) + (long)n * p.res2.sn + opix * p.res2.sp + pc;
 #pragma unroll
       for (int i = 0; i < 4; ++i)

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvParams p, const
     float v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = acc[4 * g + i];
-    convk::epilogue4(p, n, oy, ox, ct * 32 + 8 * g + 4 * hh, v);
+    convk::epilogue4<true>(p, n, oy, ox, ct * 32 + 8 * g + 4 * hh, v);
   }
 }
 

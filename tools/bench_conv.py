@@ -22,6 +22,8 @@ LAYERS = [
     ("3x3 128->512 s1 @272x480", 128, 512, 3, 1, 272, 480),
     ("7x7 32->64 s1 @1088x1920", 32, 64, 7, 1, 1088, 1920),
     ("7x7 8->32 s1 @1088x1920", 8, 32, 7, 1, 1088, 1920),
+    ("7x7 64->32 s1 @1088x1920", 64, 32, 7, 1, 1088, 1920),
+    ("7x7 32->16 s1 @1088x1920", 32, 16, 7, 1, 1088, 1920),
     ("3x3 128->128 s1 @68x120", 128, 128, 3, 1, 68, 120),
     ("3x3 128->128 s1 @34x60", 128, 128, 3, 1, 34, 60),
     ("3x3 128->128 s1 @17x30", 128, 128, 3, 1, 17, 30),
