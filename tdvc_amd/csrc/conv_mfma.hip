@@ -37,8 +37,11 @@ namespace {
 
 constexpr int TH = 8, TW = 32;
 
-template <int CK8, int MT, int STRIDE>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
+// LEAN (MT == 2 only, chosen on the host from ConvParams::simple == 2): the instantiation carries ONLY the lean
+// transposed epilogue -- with both epilogue forms and the per-register fallback inlined the MT = 2 kernels sat at 256
+// VGPRs (two workgroups per CU); the first layers (3x3 8->64 at 1080p, four per frame) are latency-bound there.
+template <int CK8, int MT, int STRIDE, bool LEAN = false>
+__global__ __launch_bounds__(256, LEAN ? 3 : 1) void conv_mfma_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CK = CK8 * 8;
   constexpr int PS = (CK8 == 1) ? 16 : CK * 2 + 16;  // LDS bytes per staged pixel
@@ -139,11 +142,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   }
 
   // ---- epilogue ------------------------------------------------------------------------------
-  if constexpr (MT == 2) {
-    if (p.simple) {       // transposed full-line stores through LDS (the staging tile is dead now)
+  if constexpr (MT == 2 && LEAN) {
+    __syncthreads();      // transposed full-line stores through LDS (the staging tile is dead now)
+    convk::epilogue_simple_rows<2, false, 2>(p, acc, p.bias + cb * 64, tile + wave * (32 * 144), n, cb * 64,
+                                             ty * TH + wave * 2, tx * TW, lane, false);
+    return;
+  } else if constexpr (MT == 2) {
+    if (p.simple) {
       __syncthreads();
-      convk::epilogue_simple_rows<2>(p, acc, p.bias + cb * 64, tile + wave * (32 * 144), n, cb * 64,
-                                     ty * TH + wave * 2, tx * TW, lane, false);
+      convk::epilogue_simple_rows<2, false, 1>(p, acc, p.bias + cb * 64, tile + wave * (32 * 144), n, cb * 64,
+                                               ty * TH + wave * 2, tx * TW, lane, false);
       return;
     }
   }
@@ -168,7 +176,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 
 template <int CK8, int MT, int STRIDE>
 int launch(const ConvParams& p, dim3 grid, size_t lds, hipStream_t st) {
-  hipLaunchKernelGGL((conv_mfma_kernel<CK8, MT, STRIDE>), grid, dim3(256), lds, st, p);
+  if constexpr (MT == 2) {
+    if (p.simple == 2) {
+      hipLaunchKernelGGL((conv_mfma_kernel<CK8, MT, STRIDE, true>), grid, dim3(256), lds, st, p);
+      return tdvc_launch_status("tdvc_conv2d");
+    }
+  }
+  hipLaunchKernelGGL((conv_mfma_kernel<CK8, MT, STRIDE, false>), grid, dim3(256), lds, st, p);
   return tdvc_launch_status("tdvc_conv2d");
 }
 
