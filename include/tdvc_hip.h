@@ -277,6 +277,19 @@ int tdvc_ar_decode_serial(const uint8_t* data, int64_t nbytes, const int32_t* cd
                           const tdvc_fmap* pc, const tdvc_conv_desc* convs, int nconvs, const tdvc_fmap* gp,
                           const int32_t* pos_table, int npos_total, int M, int W, const float* scale_table, int ntable,
                           int32_t* idx_dev, int32_t* sym_dev, void* stream);
+/* The context loop of ONE image over anti-diagonals (wavefront order), natively, in either direction.  pos_dev: device
+ * int32 [H*W][2] in wavefront order, step s owning step_sizes[s] (HOST array) consecutive entries; x1 / pc / gp and the
+ * conv descriptors' x / y maps are (1, 1, >= max step, C) staging buffers whose width is set to the step's size per step.
+ * Encoder (y != NULL, data == NULL; replaces `_compress_ar`'s position loop, main/model/pnet.py:48,72): gather -> convs ->
+ * tdvc_ar_quantize per step; sym_dev / idx_dev are raster [H][W][M]; nothing synchronises.
+ * Decoder (data != NULL, y == NULL) of a stream whose symbols were emitted in wavefront order (an extension: the
+ * reference's streams are raster-ordered, tdvc_ar_decode_serial reads those): gather -> convs -> indexes -> host range
+ * decoder -> quantise, one stream synchronisation per step; sym_dev / idx_dev are [H*W][M] in wavefront order. */
+int tdvc_ar_wavefront(const uint8_t* data, int64_t nbytes, const int32_t* cdfs, int32_t cdf_stride, const int32_t* cdf_sizes,
+                      const int32_t* offsets, const tdvc_fmap* y, const tdvc_fmap* y_hat, const tdvc_fmap* params,
+                      const tdvc_fmap* x1, const tdvc_fmap* pc, const tdvc_conv_desc* convs, int nconvs, const tdvc_fmap* gp,
+                      const int32_t* pos_dev, const int32_t* step_sizes, int nsteps, int M, int W,
+                      const float* scale_table, int ntable, int32_t* idx_dev, int32_t* sym_dev, void* stream);
 /* q[n][h][w][c] = round(z - median[c]) as int32 in the fmap's own order (factorised-prior symbols). */
 int tdvc_round_symbols(const tdvc_fmap* z, const float* median, int32_t* out, void* stream);
 

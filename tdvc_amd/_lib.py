@@ -78,6 +78,7 @@ SIGNATURES = {
     "tdvc_gc_backward": (_i, [_FM, _FM, _FM, _f, _FM, _FM, _P]),
     "tdvc_dcn_columns": (_i, [_FM, _FM, _i, _FM, _P]),
     "tdvc_ar_decode_serial": (_i, [_P, _i64, _P, _i, _P, _P, _FM, _FM, _FM, _FM, _P, _i, _FM, _P, _i, _i, _i, _P, _i, _P, _P, _P]),
+    "tdvc_ar_wavefront": (_i, [_P, _i64, _P, _i, _P, _P, _FM, _FM, _FM, _FM, _FM, _P, _i, _FM, _P, _P, _i, _i, _i, _P, _i, _P, _P, _P]),
     "tdvc_ssim_level_work_floats": (_i64, [_i] * 5),
     "tdvc_ssim_level": (_i, [_P, _P, _i, _i, _i, _i, _P, _i, _f, _f, _P, _P, _P, _i64, _P]),
     "tdvc_avgpool2_pad_f32": (_i, [_P, _i64, _i, _i, _P, _P]),

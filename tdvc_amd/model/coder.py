@@ -111,6 +111,7 @@ def subpel_conv3x3(cin, cout, r=1):
 
 
 LR = dict(act=ACT_LRELU, slope=0.01)
+STREAM_ORDERS = ("raster", "wavefront")
 
 
 class ResidualBlock(nn.Module, PackCache):
@@ -496,16 +497,17 @@ class Cheng2020Anchor(nn.Module, PackCache):
                 steps.append(ps)
         return steps
 
-    def _ar_step(self, y_hat, params, pos, n, x1, pc):
-        ops.ar_gather(y_hat, params, pos, n, x1, pc)
-        v = lambda fm, c0, C_: FM(fm.t[:, :, :n], c0, 1, C_)
-        ops.conv(v(x1, 0, x1.C), self._ctx_1x1(), out=v(pc, 2 * self.M, 2 * self.M))
-        return self.run_entropy_parameters(v(pc, 0, 4 * self.M))
-
     @torch.no_grad()
-    def compress(self, x: FM, f32=False):
+    def compress(self, x: FM, f32=False, order="raster"):
         """-> {"strings": [y_strings, z_strings], "shape": (h, w)} like compressai's compress()
-        (`f32`: the fp32-island mode, see run())"""
+        (`f32`: the fp32-island mode, see run()).
+
+        `order`: symbol order of the y stream.  "raster" is compressai's (h, w, c) order: the stream the reference writes, decoded
+        position by position.  "wavefront" emits the same symbols anti-diagonal by anti-diagonal (the order the encoder computes
+        them in, wavefront_steps()), which lets decompress() decode a whole diagonal per step: an extension, not readable by the
+        reference's decoder."""
+        if order not in STREAM_ORDERS:
+            raise ValueError(f"order must be one of {STREAM_ORDERS}, got {order!r}")
         dev = x.t.device
         ebt, gct, table = self._coder_tables()
         M = self.M
@@ -525,28 +527,31 @@ class Cheng2020Anchor(nn.Module, PackCache):
         z_strings = [ops.rans_encode(zs[b], zidx, ebt) for b in range(B)]
         steps = self.wavefront_steps(H, W)
         flat = torch.tensor([p for st in steps for p in st], dtype=torch.int32, device=dev)
-        x1 = FM.empty(1, 1, H, 12 * M, dtype=adt, device=dev)
-        pc = FM.empty(1, 1, H, 4 * M, dtype=adt, device=dev)
+        sizes = np.array([len(st) for st in steps], dtype=np.int32)
+        chain = self._ar_chain(H, adt, dev)
         y_strings, dbg = [], []
         for b in range(B):
             y_hat = FM.zeros(1, H, W, M, dtype=adt, device=dev)
             sym = torch.zeros((H, W, M), dtype=torch.int32, device=dev)
             idx = torch.zeros((H, W, M), dtype=torch.int32, device=dev)
-            o = 0
-            for st in steps:
-                n = len(st)
-                pos = flat[o:o + n]
-                gp = self._ar_step(y_hat, params.batch(b, 1), pos, n, x1, pc)
-                ops.ar_quantize(y32.batch(b, 1), gp, pos, n, table, y_hat, sym, idx)
-                o += n
-            y_strings.append(ops.rans_encode(sym.cpu().numpy(), idx.cpu().numpy(), gct))      # raster (h, w, c) order
+            # the W + 3(H-1) steps run natively (tdvc_ar_wavefront: gather -> context conv -> entropy_parameters -> quantise)
+            ops.ar_wavefront(None, None, y32.batch(b, 1), y_hat, params.batch(b, 1), chain["x1"], chain["pc"], chain["descs"], chain["gp"],
+                             flat, sizes, M, W, table, idx, sym)
+            if order == "wavefront":
+                fl = flat.long()
+                y_strings.append(ops.rans_encode(sym[fl[:, 0], fl[:, 1]].cpu().numpy(), idx[fl[:, 0], fl[:, 1]].cpu().numpy(), gct))
+            else:
+                y_strings.append(ops.rans_encode(sym.cpu().numpy(), idx.cpu().numpy(), gct))  # raster (h, w, c) order
             dbg.append({"y_hat": y_hat, "symbols": sym, "indexes": idx})
         return {"strings": [y_strings, z_strings], "shape": (z.H, z.W), "_debug": dbg}
 
     @torch.no_grad()
-    def decompress(self, strings, shape, synth=True, f32=False):
-        """strings as returned by compress(); serial raster-order context decoding (the stream order of
-        compressai's bitstream).  -> {"x_hat": FM, "y_hat": FM}.  `f32` must match the encoder's mode."""
+    def decompress(self, strings, shape, synth=True, f32=False, order="raster"):
+        """strings as returned by compress(); "raster": serial position-by-position context decoding (the stream order of
+        compressai's bitstream); "wavefront": one anti-diagonal per step (W + 3(H-1) steps instead of H*W).
+        -> {"x_hat": FM, "y_hat": FM}.  `f32` and `order` must match the encoder's."""
+        if order not in STREAM_ORDERS:
+            raise ValueError(f"order must be one of {STREAM_ORDERS}, got {order!r}")
         dev = self.context_prediction.weight.device
         adt = torch.float32 if f32 else torch.float16
         ebt, gct, table = self._coder_tables()
@@ -561,29 +566,49 @@ class Cheng2020Anchor(nn.Module, PackCache):
         z_hat = FM((zsym.float() + med).to(adt))
         params = FM.empty(B, H, W, 2 * M, dtype=adt, device=dev)
         self.run_h_s(z_hat, out=params)
-        x1 = FM.empty(1, 1, 1, 12 * M, dtype=adt, device=dev)
-        pc = FM.empty(1, 1, 1, 4 * M, dtype=adt, device=dev)
         y_hat_all = FM.zeros(B, H, W, M, dtype=adt, device=dev)
         sym = torch.zeros((H, W, M), dtype=torch.int32, device=dev)
         idx = torch.zeros((H, W, M), dtype=torch.int32, device=dev)
-        # the per-position chain as fixed conv descriptors over fixed buffers: context conv (1x1 over the gathered
-        # neighbourhood) into pc[2M:4M], entropy_parameters into gp; the loop itself runs natively
+        if order == "wavefront":
+            for b in range(B):
+                self._decode_wavefront(strings[0][b], gct, table, y_hat_all.batch(b, 1), params.batch(b, 1))
+            return {"x_hat": self.run_g_s(y_hat_all) if synth else None, "y_hat": y_hat_all}
+        # the per-position chain over one-position staging buffers; the loop itself runs natively
         # (tdvc_ar_decode_serial: Python drove it at ~230 us per position)
-        e = self.entropy_parameters
-        v = lambda fm, c0, C_: FM(fm.t, c0, 1, C_)
-        d0, _, _, _, _, _ = ops.conv_desc(v(x1, 0, x1.C), self._ctx_1x1(), out=v(pc, 2 * M, 2 * M))
-        t0 = FM.empty(1, 1, 1, ops.pad8(e[0].out_channels), dtype=adt, device=dev)
-        t1 = FM.empty(1, 1, 1, ops.pad8(e[2].out_channels), dtype=adt, device=dev)
-        gp = FM.empty(1, 1, 1, 2 * M, dtype=torch.float32, device=dev)
-        d1, _, _, _, _, _ = ops.conv_desc(v(pc, 0, 4 * M), pk_conv(self, "ep0", e[0]), out=t0, **LR)
-        d2, _, _, _, _, _ = ops.conv_desc(t0, pk_conv(self, "ep2", e[2]), out=t1, **LR)
-        d3, _, _, _, _, _ = ops.conv_desc(t1, pk_conv(self, "ep4", e[4]), out=gp, out_dtype=torch.float32)
+        chain = self._ar_chain(1, adt, dev)
         pos_table = torch.tensor([[h, w] for h in range(H) for w in range(W)], dtype=torch.int32, device=dev)
         for b in range(B):
-            ops.ar_decode_serial(strings[0][b], gct, y_hat_all.batch(b, 1), params.batch(b, 1), x1, pc, [d0, d1, d2, d3], gp, pos_table,
-                                 M, W, table, idx, sym)
+            ops.ar_decode_serial(strings[0][b], gct, y_hat_all.batch(b, 1), params.batch(b, 1), chain["x1"], chain["pc"], chain["descs"],
+                                 chain["gp"], pos_table, M, W, table, idx, sym)
         return {"x_hat": self.run_g_s(y_hat_all) if synth else None, "y_hat": y_hat_all}
 
+    def _ar_chain(self, cap, adt, dev):
+        """the per-step chain as conv descriptors over staging buffers of `cap` positions: context conv (1x1 over the gathered
+        neighbourhoods) into pc[2M:4M], entropy_parameters into gp"""
+        M, e = self.M, self.entropy_parameters
+        x1 = FM.empty(1, 1, cap, 12 * M, dtype=adt, device=dev)
+        pc = FM.empty(1, 1, cap, 4 * M, dtype=adt, device=dev)
+        t0 = FM.empty(1, 1, cap, ops.pad8(e[0].out_channels), dtype=adt, device=dev)
+        t1 = FM.empty(1, 1, cap, ops.pad8(e[2].out_channels), dtype=adt, device=dev)
+        gp = FM.empty(1, 1, cap, 2 * M, dtype=torch.float32, device=dev)
+        v = lambda fm, c0, C_: FM(fm.t, c0, 1, C_)
+        descs = [ops.conv_desc(v(x1, 0, x1.C), self._ctx_1x1(), out=v(pc, 2 * M, 2 * M))[0],
+                 ops.conv_desc(v(pc, 0, 4 * M), pk_conv(self, "ep0", e[0]), out=t0, **LR)[0],
+                 ops.conv_desc(t0, pk_conv(self, "ep2", e[2]), out=t1, **LR)[0],
+                 ops.conv_desc(t1, pk_conv(self, "ep4", e[4]), out=gp, out_dtype=torch.float32)[0]]
+        return {"x1": x1, "pc": pc, "gp": gp, "descs": descs, "keep": (t0, t1)}
+
+    def _decode_wavefront(self, data, gct, table, y_hat, params):
+        """one image of a wavefront-ordered y stream (tdvc_ar_wavefront, decoder direction)"""
+        dev, M = y_hat.t.device, self.M
+        H, W = y_hat.H, y_hat.W
+        steps = self.wavefront_steps(H, W)
+        flat = torch.tensor([p for st in steps for p in st], dtype=torch.int32, device=dev)
+        chain = self._ar_chain(H, y_hat.t.dtype, dev)
+        sym = torch.zeros((H * W, M), dtype=torch.int32, device=dev)          # wavefront order
+        idx = torch.zeros((H * W, M), dtype=torch.int32, device=dev)
+        ops.ar_wavefront(data, gct, None, y_hat, params, chain["x1"], chain["pc"], chain["descs"], chain["gp"], flat,
+                         np.array([len(st) for st in steps], dtype=np.int32), M, W, table, idx, sym)
 
 def _g_a(N):
     return nn.Sequential(

@@ -29,6 +29,9 @@ class VideoCompressor(nn.Module):
         # islands (fp32 activations + weights on v_mfma_f32_32x32x2_f32): symbols and byte streams then equal the fp32 CPU
         # reference's on identical coder inputs (tests/test_entropy_coding_gpu.py)
         self.coder_fp32 = False
+        # symbol order of the y streams encode() writes and decode() expects: "raster" (compressai's, what the reference's
+        # decoder reads) or "wavefront" (an extension: the decoder takes an anti-diagonal per step instead of a position)
+        self.stream_order = "raster"
         self.mvCoder = MVCoder(N=128)
         self.resCoder = ResCoder(N=128)
         self.extra_fea = FeaExtra(2)
@@ -164,13 +167,13 @@ class VideoCompressor(nn.Module):
         self.mvCoder.update()
         self.resCoder.update()
         f32 = self.coder_fp32
-        mv = self.mvCoder.compress(estmv, f32=f32)
+        mv = self.mvCoder.compress(estmv, f32=f32, order=self.stream_order)
         cat = lambda dbg: FM(torch.cat([d["y_hat"].t for d in dbg], 0))
         out = {}
 
         def res_y_hat(pred):
             resid = ops.scale_act_res(f_cur, FM.empty(B, H, W, 64, device=dev), res=pred, res_sign=-1.0)
-            out["res"] = self.resCoder.compress(resid, f32=f32)
+            out["res"] = self.resCoder.compress(resid, f32=f32, order=self.stream_order)
             return cat(out["res"]["_debug"])
         recon = self._reconstruct(cat(mv["_debug"]), res_y_hat, feats, refs8, iframe8)
         rs = out["res"]
@@ -185,6 +188,7 @@ class VideoCompressor(nn.Module):
         self.mvCoder.update()
         self.resCoder.update()
         f32 = self.coder_fp32
-        mv = self.mvCoder.decompress([strings[0], strings[1]], shapes[0], f32=f32)
-        return self._reconstruct(mv["y_hat"], lambda pred: self.resCoder.decompress([strings[2], strings[3]], shapes[1], synth=False, f32=f32)["y_hat"],
+        so = self.stream_order
+        mv = self.mvCoder.decompress([strings[0], strings[1]], shapes[0], f32=f32, order=so)
+        return self._reconstruct(mv["y_hat"], lambda pred: self.resCoder.decompress([strings[2], strings[3]], shapes[1], synth=False, f32=f32, order=so)["y_hat"],
                                  feats, refs8, iframe8)

@@ -910,6 +910,21 @@ def ar_decode_serial(data: bytes, t: CdfTables, y_hat: FM, params: FM, x1: FM, p
                                           idx.data_ptr(), sym.data_ptr(), _stream()), "ar_decode_serial")
 
 
+def ar_wavefront(data: bytes | None, t: CdfTables | None, y: FM | None, y_hat: FM, params: FM, x1: FM, pc: FM, descs: list, gp: FM,
+                 pos: torch.Tensor, step_sizes: np.ndarray, M: int, W: int, scale_table: torch.Tensor, idx: torch.Tensor, sym: torch.Tensor) -> None:
+    """the context loop of one image over anti-diagonals (`tdvc_ar_wavefront`): encoder with `y`, decoder with `data` + `t`"""
+    buf = np.frombuffer(data, dtype=np.uint8) if data is not None else None
+    arr = (L.ConvDesc * len(descs))(*descs)
+    ss = np.ascontiguousarray(step_sizes, dtype=np.int32)
+    dyh, dp, dx, dc, dg = y_hat.desc(), params.desc(), x1.desc(), pc.desc(), gp.desc()
+    dy = y.desc() if y is not None else None
+    L.check(L.lib().tdvc_ar_wavefront(buf.ctypes.data if buf is not None else None, buf.size if buf is not None else 0,
+                                      t.cdf.ctypes.data if t else None, t.stride if t else 0, t.sizes.ctypes.data if t else None,
+                                      t.offsets.ctypes.data if t else None, C.byref(dy) if dy is not None else None, C.byref(dyh), C.byref(dp),
+                                      C.byref(dx), C.byref(dc), arr, len(descs), C.byref(dg), pos.data_ptr(), ss.ctypes.data, ss.size, M, W,
+                                      scale_table.data_ptr(), scale_table.numel(), idx.data_ptr(), sym.data_ptr(), _stream()), "ar_wavefront")
+
+
 def ar_gather(y_hat: FM, params: FM, pos: torch.Tensor, npos: int, x1: FM, pc: FM):
     dy, dp, dx, dc = y_hat.desc(), params.desc(), x1.desc(), pc.desc()
     L.check(L.lib().tdvc_ar_gather(C.byref(dy), C.byref(dp), pos.data_ptr(), npos, C.byref(dx), C.byref(dc), _stream()), "ar_gather")

@@ -47,21 +47,34 @@ def code_gop(net, frames: torch.Tensor, enable_amp: bool = True, bitstream_dir: 
         if bitstream_dir:
             from .. import bitstream
             rl = ref_list(refs)
+            torch.cuda.synchronize()
+            t_e = time.time()
             enc = net.encode(x, rl)
+            torch.cuda.synchronize()
+            t_e = time.time() - t_e
             flat = [s[0] for s in enc["strings"]]
-            shp = [(0, 128, *enc["shapes"][i // 2]) for i in range(4)]
+            # first shape word: the reference writes the batch index (always 0); the y records of a wavefront-ordered
+            # stream carry 1 there so that a reader cannot mistake them for compressai's raster order
+            wf = int(net.stream_order == "wavefront")
+            shp = [(wf if i % 2 == 0 else 0, 128, *enc["shapes"][i // 2]) for i in range(4)]
             path = os.path.join(bitstream_dir, f"{tag}frame{t:03d}.bin")
             with open(path, "wb") as f:
                 nbytes = bitstream.write_records(f, flat, shp)
             with open(path, "rb") as f:
                 strings, shapes = bitstream.read_records(f, 4)
+            if shapes[0][0] != wf or shapes[2][0] != wf:
+                raise RuntimeError(f"{path}: stream order flag {shapes[0][0]} does not match the decoder's ({net.stream_order})")
+            t_d = time.time()
             recon = net.decode([[s] for s in strings], [shapes[0][2:], shapes[2][2:]], rl)
+            torch.cuda.synchronize()
+            t_d = time.time() - t_d
             assert torch.equal(recon, enc["recon"]), "decoder / encoder reconstruction mismatch"
             refs.append(recon)
             rc, xc = crop(recon, (h, w)), crop(x, (h, w))
             bpp = 8.0 * nbytes / (x.shape[-2] * x.shape[-1])
             stats.append({"frame": t, "psnr": psnr(rc, xc), "msssim": _msssim(rc, xc), "bpp": bpp, "bpp_mv": 8.0 * (len(flat[0]) + len(flat[1])) / (x.shape[-2] * x.shape[-1]),
-                          "bpp_res": 8.0 * (len(flat[2]) + len(flat[3])) / (x.shape[-2] * x.shape[-1]), "bytes": nbytes})
+                          "bpp_res": 8.0 * (len(flat[2]) + len(flat[3])) / (x.shape[-2] * x.shape[-1]), "bytes": nbytes,
+                          "encode_s": t_e, "decode_s": t_d})
             continue
         recon, bpp_res, bpp_mv = net(x, ref_list(refs), enable_amp)
         refs.append(recon)                                   # padded reconstruction re-enters the list (:68)
@@ -85,6 +98,8 @@ def main():
     ap.add_argument("--val-dataset", default="UVG", choices=("UVG", "MCL-JCV", "HEVC"), help="with --dataset-root (predict.py:154-166)")
     ap.add_argument("--cls", default="B", help="HEVC class A..E")
     ap.add_argument("--train-lambda", type=int, default=2048, help="selects the BPG QP of the I-frames (dataset.py:25-36)")
+    ap.add_argument("--stream-order", default="raster", choices=("raster", "wavefront"),
+                    help="with --bitstream-dir: y-symbol order (raster = the reference's; wavefront = diagonal-parallel decoding)")
     a = ap.parse_args()
     opt = {"model": "pnet", "pretrain": a.pretrain, "val_dataset": "synthetic", "class": "-", "enable_amp": True}
     if a.cfg:
@@ -102,6 +117,7 @@ def main():
     else:
         fill_parameters(net)
     net = net.to(dev).eval()
+    net.stream_order = a.stream_order
     t0 = time.time()
     stats = []
     dataset = None
@@ -131,6 +147,11 @@ def main():
         n = max(1, len(allstats))
         res = {"frames": len(allstats), "bpp": sum(s["bpp"] for s in allstats) / n,
                "psnr": sum(s["psnr"] for s in allstats) / n, "msssim": sum(s["msssim"] for s in allstats) / n, "seconds": time.time() - t0, "cfg": opt}
+        timed = [s for s in allstats if "encode_s" in s]
+        if timed:
+            res.update(stream_order=a.stream_order, encode_s_per_frame=sum(s["encode_s"] for s in timed) / len(timed),
+                       decode_s_per_frame=sum(s["decode_s"] for s in timed) / len(timed),
+                       encode_s=[round(s["encode_s"], 4) for s in timed], decode_s=[round(s["decode_s"], 4) for s in timed])
         print(json.dumps(res))
         if a.out:
             with open(a.out, "w") as f:

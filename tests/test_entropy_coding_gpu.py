@@ -139,6 +139,60 @@ def test_frame_encode_container_decode_roundtrip(report):
     assert s2 == big and tuple(sh2[0]) == (1, 2, 3, 4)
 
 
+@pytest.mark.parametrize("H,W", [(64, 64), (128, 192)])
+@pytest.mark.parametrize("f32", [False, True])
+def test_wavefront_stream_order(coders, H, W, f32, report):
+    """order="wavefront": the same symbols as the raster stream, emitted diagonal by diagonal; the oracle's python rANS
+    gives the same bytes for that symbol order, the diagonal-parallel decoder rebuilds the encoder's y_hat bit for bit,
+    and it equals what the raster decoder gets from the raster stream"""
+    from tdvc_amd import ops
+    from oracle.tdvc_ref import coder as oc
+    ref, m = coders
+    xf = to_fm(rnd16(randn(1, 64, H, W, seed=37, scale=0.5)), ops)
+    enc_r = m.compress(xf, f32=f32)
+    enc_w = m.compress(xf, f32=f32, order="wavefront")
+    dr, dw = enc_r["_debug"][0], enc_w["_debug"][0]
+    assert torch.equal(dr["symbols"], dw["symbols"]) and torch.equal(dr["indexes"], dw["indexes"])
+    assert enc_r["strings"][1] == enc_w["strings"][1]                         # z stream: untouched
+    h, w = dw["symbols"].shape[:2]
+    order = [p for st in m.wavefront_steps(h, w) for p in st]
+    assert sorted(order) == [(a, b) for a in range(h) for b in range(w)]      # a permutation of the raster positions
+    sym, idx = dw["symbols"].cpu().numpy(), dw["indexes"].cpu().numpy()
+    hs, ws = np.array([p[0] for p in order]), np.array([p[1] for p in order])
+    gc = ref.gaussian_conditional
+    want = oc.rans_encode(sym[hs, ws].reshape(-1).tolist(), idx[hs, ws].reshape(-1).tolist(), gc._quantized_cdf.tolist(),
+                          gc._cdf_length.tolist(), gc._offset.tolist())
+    assert enc_w["strings"][0][0] == want
+    dec_w = m.decompress(enc_w["strings"], enc_w["shape"], synth=False, f32=f32, order="wavefront")
+    dec_r = m.decompress(enc_r["strings"], enc_r["shape"], synth=False, f32=f32)
+    assert torch.equal(dec_w["y_hat"].t, dw["y_hat"].t) and torch.equal(dec_w["y_hat"].t, dec_r["y_hat"].t)
+    report(f"wavefront stream {H}x{W} f32={f32}: {len(enc_w['strings'][0][0])} B vs raster {len(enc_r['strings'][0][0])} B, "
+           f"{len(m.wavefront_steps(h, w))} decode steps instead of {h * w}")
+    with pytest.raises(ValueError):
+        m.compress(xf, order="zigzag")
+
+
+def test_frame_roundtrip_wavefront_order(report):
+    """VideoCompressor.stream_order = "wavefront": encode -> decode is closed-loop exact, and the reconstruction is the
+    raster stream's (the symbols are the same, only their order in the y streams differs)"""
+    from tdvc_amd import synth
+    from tdvc_amd.model import VideoCompressor
+    net = VideoCompressor()
+    synth.fill_parameters(net)
+    net = net.cuda().eval()
+    gop = synth.make_gop(78, 3, 128, 64).cuda()
+    refs = synth.ref_list([gop[0:1], gop[1:2]])
+    enc_r = net.encode(gop[2:3], refs)
+    net.stream_order = "wavefront"
+    enc_w = net.encode(gop[2:3], refs)
+    assert torch.equal(enc_r["recon"], enc_w["recon"])
+    dec = net.decode(enc_w["strings"], enc_w["shapes"], refs)
+    assert torch.equal(dec, enc_w["recon"])
+    nb = lambda e: sum(len(s[0]) for s in e["strings"])
+    report(f"frame round trip, wavefront order 128x64: {nb(enc_w)} B vs raster {nb(enc_r)} B")
+    assert abs(nb(enc_w) - nb(enc_r)) <= 16
+
+
 def test_encode_after_train_step_decodes_in_fresh_model(report):
     """encode -> one TrainStep -> encode, then decode in a FRESH model built from the saved state_dict: every packed layer
     form the entropy coder uses (the context conv's 1x1 form included) must follow the optimizer step, or a decoder in
