@@ -109,6 +109,29 @@ int tdvc_conv2d(const tdvc_conv_desc* d, void* stream);
  * when d->x.dtype == TDVC_F32, so fixed descriptor chains (tdvc_ar_decode_serial) run in either precision. */
 int tdvc_conv2d_f32(const tdvc_conv_desc* d, void* stream);
 
+/* ---------------------------------------------------------------- fused conv pair
+ * y = act2(conv2(act1(conv1(x)))) [+ x] [+ res2] for two 3x3 / stride 1 / pad 1 / 64 -> 64 convs in one launch, the
+ * intermediate map staying in LDS: `Res_Block.forward` (main/utils/utils.py:52-56: conv, ReLU, conv, + identity) and the
+ * LeakyReLU conv pairs of main/model/pnet.py:132-166.  Results equal two tdvc_conv2d launches up to the fp32 summation
+ * order (the intermediate is rounded to fp16 exactly as the stored map would be).  Inference path: nothing is kept for a
+ * backward pass. */
+typedef struct {
+  tdvc_fmap x, y;         /* fp16 maps of 64 channels, same geometry; views (sp > 64) allowed; not in place */
+  const void* w;          /* tdvc_pack_conv_pair_weights, on the device */
+  const float* bias;      /* [2][64] on the device: conv1 | conv2 */
+  int32_t act1; float slope1;   /* TDVC_ACT_NONE / RELU / LRELU after conv1 */
+  int32_t act2; float slope2;   /* ... after conv2, before the additions */
+  int32_t add_input;      /* 1: y += x */
+  tdvc_fmap res2;         /* optional further residual (fp16, output geometry); p == NULL: none */
+} tdvc_conv_pair_desc;
+int64_t tdvc_conv_pair_packed_bytes(void);
+/* host-side packing of the two fp32 OIHW [64][64][3][3] weights into per-wave v_mfma_f32_16x16x32_f16 A fragments
+ * (layout in tdvc_amd/csrc/conv_pair.hip); dst: tdvc_conv_pair_packed_bytes() bytes of host memory, caller uploads */
+int tdvc_pack_conv_pair_weights(const float* w1_oihw, const float* w2_oihw, uint16_t* dst);
+/* 1 when tdvc_conv_pair takes this descriptor (geometry / size limits), 0: run the two convs through tdvc_conv2d */
+int tdvc_conv_pair_supported(const tdvc_conv_pair_desc* d);
+int tdvc_conv_pair(const tdvc_conv_pair_desc* d, void* stream);
+
 /* ---------------------------------------------------------------- deformable conv (motion compensation)
  * Fused modulated deformable 3x3 conv, fp16 NHWC, no column buffer:
  * replaces DCN.forward's `_DCNv2.apply` (main/utils/dcnv2/dcn_v2_amp.py:219-234) =

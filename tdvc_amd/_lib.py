@@ -38,6 +38,11 @@ class DcnDesc(C.Structure):
                 ("groups", C.c_int32), ("act", C.c_int32), ("slope", C.c_float), ("round_before_act", C.c_int32), ("x_planar", C.c_void_p)]
 
 
+class ConvPairDesc(C.Structure):
+    _fields_ = [("x", FMapDesc), ("y", FMapDesc), ("w", C.c_void_p), ("bias", C.c_void_p), ("act1", C.c_int32), ("slope1", C.c_float),
+                ("act2", C.c_int32), ("slope2", C.c_float), ("add_input", C.c_int32), ("res2", FMapDesc)]
+
+
 _P = C.c_void_p
 _FM = C.POINTER(FMapDesc)
 _i, _f, _i64 = C.c_int, C.c_float, C.c_int64
@@ -90,6 +95,10 @@ SIGNATURES = {
     "tdvc_gdn_backward": (_i, [_FM, _FM, _FM, _i, _FM, _FM, _P]),
     "tdvc_mul2_accumulate": (_i, [_FM, _FM, _FM, _P]),
     "tdvc_dcn_fused": (_i, [C.POINTER(DcnDesc), _P]),
+    "tdvc_conv_pair_packed_bytes": (_i64, []),
+    "tdvc_pack_conv_pair_weights": (_i, [_P, _P, _P]),
+    "tdvc_conv_pair_supported": (_i, [C.POINTER(ConvPairDesc)]),
+    "tdvc_conv_pair": (_i, [C.POINTER(ConvPairDesc), _P]),
     "tdvc_dcn_v2_forward_f32": (_i, [_P] * 6 + [_i] * 14 + [_P]),
     "tdvc_dcn_v2_backward_f32": (_i, [_P] * 12 + [_i] * 14 + [_P]),
     "tdvc_nchw_to_fmap": (_i, [_P, _i, _FM, _P]),

@@ -1,0 +1,493 @@
+// conv_pair — two chained 3x3 / stride 1 / pad 1 / 64 -> 64 convs in ONE launch, the intermediate map never leaving the CU:
+//     y = act2(conv2(act1(conv1(x)))) [+ x] [+ res2]
+// (`Res_Block`, main/utils/utils.py:43-56: ReLU between, identity added; the conv pairs of flownet.py / pnet.py with
+// LeakyReLU on both).  As two launches of conv_mfma_v10 the pair moves 5 maps through HBM (x, t, t, x, y: 640 B per pixel)
+// and each launch sits on the per-CU memory rate with its MFMA pipes half idle ("What bounds the 64-channel
+// 3x3 class").  Fusing through LDS needs both weight sets on chip (2 x 72 KB) next to the tiles: they do not fit in 160 KB
+// of LDS -- but they fit in REGISTERS once the work is split by output channel:
+//
+//   * 4 waves, one per SIMD (up to 512 VGPRs).  Wave w owns output channels [16w, 16w + 16) of BOTH convs and keeps their
+//     weights as v_mfma_f32_16x16x32_f16 A fragments: 2 convs x 9 taps x 2 chunks of 32 input channels = 36 fragments =
+//     144 VGPRs, loaded once per launch.  LDS holds activations only.
+//   * row streaming.  A workgroup walks a strip of 30 output columns top to bottom.  Per step one input row (34 px, by
+//     LDS-DMA into a 16-row ring, 8 rows ahead) enters conv1: its B fragments (16 px x 32 channels) feed the three live
+//     rows of t (dy = 0, 1, 2: three rotating accumulator rows).  The finished row of t (32 px) is written to a small LDS
+//     ring as fp16 -- what the unfused path stores to HBM -- and one step later enters conv2 the same way; the finished
+//     row of y picks up the identity from the input ring, goes through an LDS staging row and leaves as full 128-byte
+//     lines.  No tile epilogue, no halo recompute in y (2 of 32 conv2 columns are waste: 97 % useful MFMAs); the vertical
+//     halo costs 5 extra steps per strip segment.
+//   * per step and wave: 72 MFMAs (1152 cycles), 24 ds_read_b128, ~40 other vector instructions, one s_barrier; per CU
+//     4.4 KB in + 3.8 KB out per step = 7 B per cycle at full MFMA rate -- under the ~10 B per cycle a CU can move.
+//   * HBM traffic of the pair: x once (+ 13 % column halo, mostly L2 hits) and y once: 256 B per pixel instead of 640.
+//
+// LDS image of a ring row: pixel-major, 128 B per pixel (64 channels), the 16-byte chunk c of pixel q stored at slot
+// c ^ ((q >> 1) & 7): the ds_read_b128 of a B fragment (lane = pixel l & 15, channel block l >> 4) is then conflict-free on
+// the 4 x 16-lane groups of that instruction.  For the DMA-written input rows the XOR sits on the SOURCE address.
+#include <type_traits>
+
+#include "conv_common.h"
+
+namespace {
+
+constexpr int PW = 30;                       // output columns per strip
+constexpr int ROWB = 5120;                   // ring row: 40 pixel slots x 128 B = 5 DMA pieces of 1 KB (34 used)
+constexpr int XRING = 16, TRING = 4, PF = 8; // input ring rows, t ring rows, DMA distance in rows
+constexpr int X0 = 0, T0 = XRING * ROWB, S0 = T0 + TRING * ROWB, SROW = 4096;
+constexpr int LDS_PAIR = S0 + 2 * SROW;      // 110 592 B
+constexpr int NTHR = 256;
+
+struct PairParams {
+  const half_t* x; long x_sn; int x_sp;
+  half_t* y; long y_sn; int y_sp;
+  const half_t* res2; long r2_sn; int r2_sp;
+  const half_t* w;          // [conv 2][wave 4][tap*2 + chunk 18][lane 64][8] halves (tdvc_pack_conv_pair_weights)
+  const float* bias;        // [2][64]
+  const half_t* zeros;      // >= 16 B of zeros: DMA source of out-of-image pixels
+  half_t* dump;             // 4 KB nobody reads: store target of the lanes outside a strip (keeps the store branch-free)
+  int N, H, W;
+  int strips, segs, seg_rows, jobs;
+  float slope1, slope2;     // max(v, v * slope): 1 = none, 0 = ReLU, else LeakyReLU
+  int experiment;           // timing diagnostics (tdvc_debug_set_pair_experiment): 1 no DMA after the prologue, 2 stores to the dump line, 4 no barrier
+};
+
+__device__ __forceinline__ void glds16(const half_t* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void pair_barrier(bool skip = false) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (!skip) __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+template <int A>
+__device__ __forceinline__ half4 actk(half4 v, half4 sl) {
+  if constexpr (A == 1) {
+    const half4 z = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+    return __builtin_elementwise_max(v, z);
+  } else if constexpr (A == 2) {
+    return __builtin_elementwise_max(v, v * sl);
+  } else {
+    return v;
+  }
+}
+
+// A1 / A2: activation after conv1 / conv2: 0 none, 1 ReLU, 2 max(v, v * slope) (LeakyReLU; slope 1 = none)
+template <int A1, int A2, bool ADDX, bool RES2, bool STAMP = false>
+__global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, long long* stamps = nullptr, int stamp_cap = 0) {
+  long long st_busy = 0, st_vm = 0, st_bar = 0, st_a = 0, st_t0 = 0, st_n = 0;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kb = lane >> 4;
+
+  // ---- this wave's 16 output channels of both convs: 36 A fragments in registers for the whole launch
+  half8 wf[2][18];
+#pragma unroll
+  for (int cv = 0; cv < 2; ++cv)
+#pragma unroll
+    for (int f = 0; f < 18; ++f) wf[cv][f] = *reinterpret_cast<const half8*>(p.w + ((((long)(cv * 4 + wave) * 18 + f) * 64 + lane) * 8));
+  const f32x4 bias1 = *reinterpret_cast<const f32x4*>(p.bias + 16 * wave + 4 * kb);       // C/D rows 4 kb + i of this wave's block
+  const f32x4 bias2 = *reinterpret_cast<const f32x4*>(p.bias + 64 + 16 * wave + 4 * kb);
+
+  // ---- per-lane LDS offsets inside a ring row
+  int foff[3][2];                              // B fragment (dx, channel chunk) of column block 0: pixel dx + (l & 15); block 1 sits
+#pragma unroll                                 // 16 pixels = 2048 B further (16 pixels do not change the swizzle term)
+  for (int dx = 0; dx < 3; ++dx) {
+    const int q = dx + r16, sw = (q >> 1) & 7;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) foff[dx][kc] = q * 128 + (((4 * kc + kb) ^ sw) << 4);
+  }
+  int doff[2], roff[2];                        // C/D layout (pixel l & 15, channels 16 w + 4 kb ..+3): t / staging write, identity read
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int q = 16 * cb + r16, c = 2 * wave + (kb >> 1);
+    doff[cb] = q * 128 + ((c ^ ((q >> 1) & 7)) << 4) + 8 * (kb & 1);
+    const int qx = q + 2;                      // output column yi sits at input pixel yi + 2
+    roff[cb] = qx * 128 + ((c ^ ((qx >> 1) & 7)) << 4) + 8 * (kb & 1);
+  }
+  // DMA items: piece j of a row covers pixels 8 j .. 8 j + 7 (lane: slot lane & 7 of pixel 8 j + (lane >> 3)).  Every step
+  // each wave sends piece `wave` of the row 8 steps ahead; piece 4 (pixels 32, 33) goes round the waves
+  int soff_own, soff_4;
+  {
+    const int q = 8 * wave + (lane >> 3), c = (lane & 7) ^ ((q >> 1) & 7);
+    soff_own = q * p.x_sp + c * 8;
+    const int q4 = 32 + (lane >> 3), c4 = (lane & 7) ^ ((q4 >> 1) & 7);
+    soff_4 = q4 * p.x_sp + c4 * 8;
+  }
+  // store item: thread = (output column tid >> 3, slot tid & 7)
+  const int s_yi = tid >> 3, s_c = (tid & 7) ^ ((s_yi >> 1) & 7);
+
+  // ---- XCD-aware job walk: workgroup b sits on XCD b % 8; an XCD takes a contiguous range of jobs (neighbouring strips
+  // of one row segment share their column halo in that XCD's L2)
+  const int nwg = (int)gridDim.x, b = (int)blockIdx.x;
+  int jfirst, jstep, jend;
+  if ((nwg & 7) == 0) {
+    const int per = (p.jobs + 7) >> 3;
+    jfirst = (b & 7) * per + (b >> 3);
+    jstep = nwg >> 3;
+    jend = min(p.jobs, ((b & 7) + 1) * per);
+  } else {
+    jfirst = b; jstep = nwg; jend = p.jobs;
+  }
+
+  // activations as max(v, v * slope) in packed fp16 (slope 1: none, 0: ReLU), what the two-launch path computes
+  const half_t hs1 = (half_t)p.slope1, hs2 = (half_t)p.slope2;
+  const half4 sl1 = {hs1, hs1, hs1, hs1}, sl2 = {hs2, hs2, hs2, hs2};
+  f32x4 a1[3][2], a2[3][2];                    // rotating accumulator rows of t and y
+  half8 fbx[12], fbt[12];                      // B fragments of the current x row / t row
+  half8 r2v = {};
+
+  for (int job = jfirst; job < jend; job += jstep) {
+    const int n = job / (p.strips * p.segs);
+    const int rem = job - n * (p.strips * p.segs);
+    const int seg = rem / p.strips, strip = rem - seg * p.strips;
+    const int c0 = strip * PW, ra = seg * p.seg_rows, rb = min(p.H, ra + p.seg_rows);
+    const int rows = rb - ra;
+    const half_t* xn = p.x + (long)n * p.x_sn;
+    half_t* yn = p.y + (long)n * p.y_sn;
+
+    bool col_own, col_4;                       // this lane's pixel of its pieces is inside the image (and one of the 34)
+    {
+      const int q = 8 * wave + (lane >> 3), q4 = 32 + (lane >> 3);
+      col_own = c0 - 2 + q >= 0 && c0 - 2 + q < p.W;
+      col_4 = q4 < 34 && c0 - 2 + q4 < p.W;
+    }
+    // t columns outside the image are the zero padding of conv2
+    unsigned tmask[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int col = c0 - 1 + 16 * cb + r16;
+      tmask[cb] = (col >= 0 && col < p.W) ? 0xFFFFFFFFu : 0u;
+    }
+    const bool s_ok = s_yi < PW && c0 + s_yi < p.W && !(p.experiment & 2);
+    // rows above the segment never finish a valid chain; start them from zero rather than from whatever the registers hold
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) { a1[s3][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; a2[s3][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    // x row ra - 2 + kk into ring slot kk & 15: this wave's piece, plus piece 4 when it is this wave's turn; returns the
+    // number of DMA instructions issued
+    auto issue_row = [&](int kk) __attribute__((always_inline)) -> int {
+      const int row = ra - 2 + kk;
+      const bool rowok = row >= 0 && row < p.H;
+      const half_t* base = xn + ((long)row * p.W + (c0 - 2)) * p.x_sp;
+      const unsigned dst = lds0 + X0 + (kk & (XRING - 1)) * ROWB;
+      glds16((rowok && col_own) ? base + soff_own : p.zeros, dst + wave * 1024);
+      if (wave == (kk & 3)) {
+        glds16((rowok && col_4) ? base + soff_4 : p.zeros, dst + 4 * 1024);
+        return 2;
+      }
+      return 1;
+    };
+    auto load_frags = [&](half8 (&fb)[12], unsigned rowbase) __attribute__((always_inline)) {
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+          const unsigned char* b0 = smem + (rowbase + foff[dx][kc]);      // one address per (dx, kc); the column block is an
+#pragma unroll                                                           // immediate offset of the read
+          for (int cb = 0; cb < 2; ++cb) fb[(cb * 3 + dx) * 2 + kc] = *reinterpret_cast<const half8*>(b0 + cb * 2048);
+        }
+    };
+
+    // ---- prologue: the first PF rows, two per wave; everything landed and visible before step 0
+#pragma unroll
+    for (int kk = 0; kk < PF; ++kk)
+      if (kk <= rows + 3) issue_row(kk);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pair_barrier();
+    load_frags(fbx, X0);                       // x row of step 0
+
+    const int K = rows + 6;
+    unsigned hist = 0;                         // vector-memory operations this wave issued in each of the last four steps (one byte each)
+    // Before a step's barrier: everything this wave sent more than four steps ago has landed (row k + 4 is read from step
+    // k + 3 on); the operations of the last four steps -- their number is tracked exactly -- may stay in flight.  Vector
+    // memory operations of a wave complete in order on this architecture (one counter for loads and stores).
+    auto land_wait = [&](int nvm) __attribute__((always_inline)) {
+      hist = (hist << 8) | (unsigned)nvm;
+      const unsigned sum = (hist & 0xFFu) + ((hist >> 8) & 0xFFu) + ((hist >> 16) & 0xFFu) + (hist >> 24);
+      switch (sum) {
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      }
+    };
+    // One step.  FULL: the steady state (6 <= k <= rows + 2), where every part of the step is active: straight-line code
+    // but for the DMA turn, so that the scheduler can lay reads, packs and stores under the 72 MFMAs.
+    auto step = [&](auto PHc, auto FULLc, int k) __attribute__((always_inline)) {
+      constexpr int PH = decltype(PHc)::value;       // k % 3: which accumulator row is new / mid / done
+      constexpr bool FULL = decltype(FULLc)::value;
+      constexpr int NEW = (PH + 1) % 3, MID = PH, DONE = (PH + 2) % 3;
+      const int i = ra - 2 + k;                // x row of this step
+      long long t0 = 0, t1 = 0, t2 = 0, ta = 0;
+      if constexpr (STAMP && FULL) t0 = clock64();       // lgkmcnt is 0 here (pair_barrier): the read costs nothing
+
+      // (b) the y row finished last step: out of the staging row now, to memory at the end of the step
+      int nvm = 0;
+      const int srow = ra + k - 6;
+      const bool have_row = FULL || (srow >= ra && srow < rb);
+      half8 yv = {};
+      if (have_row) yv = *reinterpret_cast<const half8*>(smem + S0 + ((k - 1) & 1) * SROW + tid * 16);
+      // (c) conv1: x row i feeds t rows i + 1 (dy 0, new), i (dy 1), i - 1 (dy 2, finished here)
+      const bool c1 = FULL || k <= rows + 3, c2 = FULL || (k >= 3 && k <= rows + 4);
+      if (c2) load_frags(fbt, T0 + ((k - 2) & (TRING - 1)) * ROWB);      // t row i - 2, written last step
+      if (c1) {
+#pragma unroll
+        for (int dyo = 0; dyo < 3; ++dyo) {
+          const int dy = 2 - dyo;              // the finishing row first: its pack / write overlaps the other MFMAs
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+              for (int cb = 0; cb < 2; ++cb) {
+                const int slot = dy == 2 ? DONE : (dy == 1 ? MID : NEW);
+                const bool first = dy == 0 && dx == 0 && kc == 0;
+                a1[slot][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][(dy * 3 + dx) * 2 + kc], fbx[(cb * 3 + dx) * 2 + kc],
+                                                                       first ? bias1 : a1[slot][cb], 0, 0, 0);
+              }
+          if (dy == 2) {                       // t row i - 1 -> fp16, activation, zero outside the image, into the t ring
+            const int trow = i - 1;
+            const unsigned rowm = (trow >= 0 && trow < p.H) ? 0xFFFFFFFFu : 0u;
+            unsigned char* tb = smem + T0 + ((k - 1) & (TRING - 1)) * ROWB;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+              const f32x4 v = a1[DONE][cb];
+              half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+              h = actk<A1>(h, sl1);
+              typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+              u32x2 u = __builtin_bit_cast(u32x2, h);
+              const unsigned m = rowm & tmask[cb];
+              u[0] &= m; u[1] &= m;
+              *reinterpret_cast<u32x2*>(tb + doff[cb]) = u;
+            }
+          }
+        }
+      }
+      if constexpr (FULL) {                    // 13 LDS reads (staging + t fragments) under the first 26 MFMAs of conv1
+#pragma unroll
+        for (int g = 0; g < 13; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (STAMP) { ta = clock64(); __builtin_amdgcn_sched_barrier(0); }
+      }
+      // (d) next step's x fragments (its row landed >= 3 steps ago), then conv2 on t row i - 2: y rows i - 1, i - 2, i - 3 (finished)
+      if (FULL || k + 1 <= rows + 3) load_frags(fbx, X0 + ((k + 1) & (XRING - 1)) * ROWB);
+      if (c2) {
+#pragma unroll
+        for (int dyo = 0; dyo < 3; ++dyo) {
+          const int dy = 2 - dyo;
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+              for (int cb = 0; cb < 2; ++cb) {
+                // y rows rotate one step behind t rows: y row (i - 2) + 1 - dy
+                const int slot = dy == 2 ? MID : (dy == 1 ? NEW : DONE);
+                const bool first = dy == 0 && dx == 0 && kc == 0;
+                a2[slot][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][(dy * 3 + dx) * 2 + kc], fbt[(cb * 3 + dx) * 2 + kc],
+                                                                       first ? bias2 : a2[slot][cb], 0, 0, 0);
+              }
+          if (dy == 2) {                       // y row i - 3 -> fp16, activation, + identity (x row i - 3 is still in the ring)
+            unsigned char* sb = smem + S0 + (k & 1) * SROW;
+            const unsigned char* xb = smem + X0 + ((k - 3) & (XRING - 1)) * ROWB;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+              const f32x4 v = a2[MID][cb];
+              half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+              h = actk<A2>(h, sl2);
+              if constexpr (ADDX) h = h + *reinterpret_cast<const half4*>(xb + roff[cb]);
+              *reinterpret_cast<half4*>(sb + doff[cb]) = h;
+            }
+          }
+        }
+      }
+      if constexpr (FULL) {                    // 12 x fragments + 2 identity reads under the first 28 MFMAs of conv2
+#pragma unroll
+        for (int g = 0; g < 14; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
+      // (e) vector memory at the END of the step, behind the last LDS reads: an LDS-DMA piece costs 100-185 cycles of issue
+      // among ds_reads and 25-60 in a gap without them (MI355X_MICROARCH.md, constants), and a wave alone on its SIMD pays
+      // every one of those cycles: the row PF steps ahead (this wave's piece), then the finished y row (lanes outside the
+      // strip write to a dump line: no branch)
+      if constexpr (FULL) __builtin_amdgcn_sched_barrier(0);
+      if (k + PF <= rows + 3 && !(p.experiment & 1)) nvm = issue_row(k + PF);
+      if (have_row) {
+        if constexpr (RES2) yv = yv + r2v;
+        half_t* dst = s_ok ? yn + ((long)srow * p.W + c0 + s_yi) * p.y_sp + s_c * 8 : p.dump + tid * 8;
+        *reinterpret_cast<half8*>(dst) = yv;
+        ++nvm;
+      }
+      if constexpr (RES2) {
+        const int nrow = srow + 1;
+        const bool ok = s_ok && (FULL || (nrow >= ra && nrow < rb));
+        const half_t* src = ok ? p.res2 + (long)n * p.r2_sn + ((long)nrow * p.W + c0 + s_yi) * p.r2_sp + s_c * 8 : p.zeros;
+        r2v = *reinterpret_cast<const half8*>(src);
+        ++nvm;
+      }
+      if constexpr (STAMP && FULL) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        t1 = clock64();
+      }
+      land_wait(nvm);
+      if constexpr (STAMP && FULL) t2 = clock64();
+      pair_barrier((p.experiment & 4) != 0);
+      if constexpr (STAMP && FULL) {
+        const long long t3 = clock64();
+        st_busy += t1 - t0; st_vm += t2 - t1; st_bar += t3 - t2; st_a += ta - t0; st_n += 1;
+      }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    auto edge_steps = [&](int k, int kend) __attribute__((always_inline)) {   // k % 3 == 0
+      for (; k < kend; k += 3) {
+        step(I0{}, std::false_type{}, k);
+        if (k + 1 < kend) step(I1{}, std::false_type{}, k + 1);
+        if (k + 2 < kend) step(I2{}, std::false_type{}, k + 2);
+      }
+    };
+    edge_steps(0, 6);
+    int k = 6;
+    for (; k + 2 <= rows + 2; k += 3) {
+      step(I0{}, std::true_type{}, k);
+      step(I1{}, std::true_type{}, k + 1);
+      step(I2{}, std::true_type{}, k + 2);
+    }
+    edge_steps(k, K);
+  }
+  if constexpr (STAMP) {
+    if (lane == 0 && (int)blockIdx.x < stamp_cap) {
+      long long* o = stamps + ((long)blockIdx.x * 4 + wave) * 8;
+      o[0] = st_busy; o[1] = st_vm; o[2] = st_bar; o[3] = st_a; o[4] = st_n;
+    }
+  }
+  (void)st_t0;
+}
+
+}  // namespace
+
+static bool g_pair_enabled = true;
+static int g_pair_experiment = 0;
+static long long* g_pair_stamps = nullptr;
+static int g_pair_stamp_cap = 0;
+// diagnostics: [workgroup][wave][8] int64 = {busy, vmcnt wait, barrier wait, conv1 phase, steps} cycle sums over the steady-state steps
+extern "C" void tdvc_debug_set_stamp_buffer_pair(void* buf, int cap_blocks) { g_pair_stamps = (long long*)buf; g_pair_stamp_cap = cap_blocks; }
+extern "C" void tdvc_debug_set_pair_experiment(int e) { g_pair_experiment = e; }
+// tests and A/B benchmarks: 0 makes tdvc_conv_pair_supported() answer no (callers then run the two convs separately)
+extern "C" void tdvc_debug_enable_conv_pair(int enable) { g_pair_enabled = enable != 0; }
+
+extern "C" int64_t tdvc_conv_pair_packed_bytes(void) { return 2L * 4 * 18 * 64 * 8 * 2; }
+
+// Host-side packing: two fp32 [64][64][3][3] (OIHW) weights -> the per-wave A fragments of v_mfma_f32_16x16x32_f16:
+// dst[conv][wave][tap * 2 + chunk][lane][j] = w[cout = 16 wave + (lane & 15)][cin = 32 chunk + 8 (lane >> 4) + j][tap]
+extern "C" int tdvc_pack_conv_pair_weights(const float* w1_oihw, const float* w2_oihw, uint16_t* dst) {
+  TDVC_CHECK(w1_oihw && w2_oihw && dst, "tdvc_pack_conv_pair_weights: null argument");
+  for (int cv = 0; cv < 2; ++cv) {
+    const float* w = cv ? w2_oihw : w1_oihw;
+    for (int wv = 0; wv < 4; ++wv)
+      for (int f = 0; f < 18; ++f)
+        for (int ln = 0; ln < 64; ++ln)
+          for (int j = 0; j < 8; ++j) {
+            const int co = 16 * wv + (ln & 15), ci = 32 * (f & 1) + 8 * (ln >> 4) + j, t = f >> 1;
+            const _Float16 h = (_Float16)w[((long)co * 64 + ci) * 9 + t];
+            uint16_t bits;
+            memcpy(&bits, &h, 2);
+            dst[((((long)(cv * 4 + wv) * 18 + f) * 64) + ln) * 8 + j] = bits;
+          }
+  }
+  return TDVC_OK;
+}
+
+extern "C" int tdvc_conv_pair_supported(const tdvc_conv_pair_desc* d) {
+  static const bool off = getenv("TDVC_NO_CONV_PAIR") != nullptr;
+  if (off || !g_pair_enabled || !d) return 0;
+  const tdvc_fmap &x = d->x, &y = d->y;
+  const bool ok = fmap_ok16(x) && fmap_ok16(y) && x.C == 64 && y.C == 64 && x.N == y.N && x.H == y.H && x.W == y.W && d->w && d->bias &&
+                  (!d->res2.p || (fmap_ok16(d->res2) && d->res2.C == 64 && d->res2.N == x.N && d->res2.H == x.H && d->res2.W == x.W)) &&
+                  (long)x.H * x.W >= 8192 && x.H >= 16;
+  return ok ? 1 : 0;
+}
+
+extern "C" int tdvc_conv_pair(const tdvc_conv_pair_desc* d, void* stream) {
+  TDVC_CHECK(d, "tdvc_conv_pair: null descriptor");
+  TDVC_CHECK(fmap_ok16(d->x) && fmap_ok16(d->y) && d->x.C == 64 && d->y.C == 64, "tdvc_conv_pair: x and y must be fp16 maps of 64 channels");
+  TDVC_CHECK(d->x.N == d->y.N && d->x.H == d->y.H && d->x.W == d->y.W, "tdvc_conv_pair: x / y geometry mismatch");
+  TDVC_CHECK(d->w && d->bias, "tdvc_conv_pair: weights / bias missing");
+  TDVC_CHECK(!d->res2.p || (fmap_ok16(d->res2) && d->res2.C == 64 && d->res2.N == d->x.N && d->res2.H == d->x.H && d->res2.W == d->x.W),
+             "tdvc_conv_pair: res2 must be an fp16 map of the output geometry");
+  TDVC_CHECK(d->x.p != d->y.p, "tdvc_conv_pair: in-place operation is not supported (rows of x are re-read as halo)");
+  auto slope_of = [](int act, float slope) { return act == TDVC_ACT_NONE ? 1.f : (act == TDVC_ACT_RELU ? 0.f : slope); };
+  TDVC_CHECK((d->act1 == TDVC_ACT_NONE || d->act1 == TDVC_ACT_RELU || d->act1 == TDVC_ACT_LRELU) &&
+             (d->act2 == TDVC_ACT_NONE || d->act2 == TDVC_ACT_RELU || d->act2 == TDVC_ACT_LRELU), "tdvc_conv_pair: activations are none / ReLU / LeakyReLU");
+  static half_t* zeros = nullptr;        // [0, 256): zeros; [256, 256 + 4096): dump lines
+  if (!zeros) {
+    hipError_t err = hipMalloc(reinterpret_cast<void**>(&zeros), 256 + 4096);
+    if (err == hipSuccess) err = hipMemset(zeros, 0, 256 + 4096);
+    if (err != hipSuccess) { zeros = nullptr; tdvc_set_error("tdvc_conv_pair: zero page allocation failed: %s", hipGetErrorString(err)); return (int)err; }
+  }
+  PairParams p;
+  p.x = reinterpret_cast<const half_t*>(d->x.p); p.x_sn = d->x.sn; p.x_sp = d->x.sp;
+  p.y = reinterpret_cast<half_t*>(d->y.p); p.y_sn = d->y.sn; p.y_sp = d->y.sp;
+  p.res2 = reinterpret_cast<const half_t*>(d->res2.p); p.r2_sn = d->res2.p ? d->res2.sn : 0; p.r2_sp = d->res2.p ? d->res2.sp : 0;
+  p.w = reinterpret_cast<const half_t*>(d->w);
+  p.bias = d->bias;
+  p.zeros = zeros;
+  p.experiment = g_pair_experiment;
+  p.dump = zeros + 128;
+  p.N = d->x.N; p.H = d->x.H; p.W = d->x.W;
+  p.slope1 = slope_of(d->act1, d->slope1);
+  p.slope2 = slope_of(d->act2, d->slope2);
+  p.strips = (p.W + PW - 1) / PW;
+  // row segments: fill 256 workgroups evenly; a segment pays 5 extra steps for its vertical halo
+  const long base = (long)p.N * p.strips;
+  int best = 1;
+  double best_eff = 0.;
+  for (int sg = 1; sg <= 64 && (p.H + sg - 1) / sg >= 16; ++sg) {
+    const int sr = (p.H + sg - 1) / sg, nseg = (p.H + sr - 1) / sr;
+    const long jobs = base * nseg;
+    const double eff = (double)jobs / (double)(((jobs + 255) / 256) * 256) * sr / (sr + 5.0);
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = sg; }
+  }
+  p.seg_rows = (p.H + best - 1) / best;
+  p.segs = (p.H + p.seg_rows - 1) / p.seg_rows;
+  p.jobs = (int)(base * p.segs);
+  const int grid = p.jobs < 256 ? p.jobs : 256;
+  auto go = [&](auto kern) -> int {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_PAIR);
+    if (err != hipSuccess) { tdvc_set_error("tdvc_conv_pair: hipFuncSetAttribute failed: %s", hipGetErrorString(err)); return (int)err; }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), LDS_PAIR, reinterpret_cast<hipStream_t>(stream), p, g_pair_stamps, g_pair_stamp_cap);
+    return 0;
+  };
+  // specialised: ReLU / none (Res_Block); everything else through the slope form
+  const bool resblock = d->act1 == TDVC_ACT_RELU && d->act2 == TDVC_ACT_NONE;
+  const int sel = (resblock ? 4 : 0) + (d->add_input ? 2 : 0) + (d->res2.p ? 1 : 0);
+  int rc;
+  switch (sel) {
+    case 0: rc = go(&conv_pair_kernel<2, 2, false, false>); break;
+    case 1: rc = go(&conv_pair_kernel<2, 2, false, true>); break;
+    case 2: rc = go(&conv_pair_kernel<2, 2, true, false>); break;
+    case 3: rc = go(&conv_pair_kernel<2, 2, true, true>); break;
+    case 4: rc = go(&conv_pair_kernel<1, 0, false, false>); break;
+    case 5: rc = go(&conv_pair_kernel<1, 0, false, true>); break;
+    case 6: rc = g_pair_stamps ? go(&conv_pair_kernel<1, 0, true, false, true>) : go(&conv_pair_kernel<1, 0, true, false>); break;
+    default: rc = go(&conv_pair_kernel<1, 0, true, true>); break;
+  }
+  if (rc) return rc;
+  return tdvc_launch_status("tdvc_conv_pair");
+}

@@ -437,6 +437,69 @@ def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, 
     return ret
 
 
+# ----------------------------------------------------------------------------- fused conv pair (inference)
+class PackedConvPair:
+    """two 3x3 64->64 convs packed for `tdvc_conv_pair` (per-wave v_mfma_f32_16x16x32_f16 A fragments + both biases)"""
+
+    def __init__(self, w: torch.Tensor, bias: torch.Tensor):
+        self.w, self.bias = w, bias
+
+
+def pack_conv_pair(w1: torch.Tensor, b1: torch.Tensor | None, w2: torch.Tensor, b2: torch.Tensor | None) -> PackedConvPair:
+    """weights (64, 64, 3, 3) on the device -> [conv][wave][tap*2 + chunk][lane][8] fp16 (the layout of
+    tdvc_pack_conv_pair_weights: cout = 16 wave + (lane & 15), cin = 32 chunk + 8 (lane >> 4) + j)"""
+    for w in (w1, w2):
+        if tuple(w.shape) != (64, 64, 3, 3):
+            raise L.TdvcHipError(f"pack_conv_pair: weights must be (64, 64, 3, 3), got {tuple(w.shape)}")
+    frag = lambda w: w.detach().float().reshape(4, 16, 2, 4, 8, 9).permute(0, 5, 2, 3, 1, 4)
+    w = torch.stack([frag(w1), frag(w2)]).contiguous().to(torch.float16)
+    zb = lambda b_: torch.zeros(64, device=w1.device) if b_ is None else b_.detach().float()
+    return PackedConvPair(w, torch.cat([zb(b1), zb(b2)]).contiguous())
+
+
+def _pair_desc(x: FM, pp: PackedConvPair, out: FM, act1, slope1, act2, slope2, add_input, res2):
+    d = L.ConvPairDesc()
+    d.x, d.y = x.desc(), out.desc()
+    d.w, d.bias = pp.w.data_ptr(), pp.bias.data_ptr()
+    d.act1, d.slope1, d.act2, d.slope2 = act1, slope1, act2, slope2
+    d.add_input = 1 if add_input else 0
+    d.res2 = res2.desc() if res2 is not None else L.FMapDesc()
+    return d
+
+
+def conv_pair_supported(x: FM, out: FM | None = None, res2: FM | None = None) -> bool:
+    """inference only (nothing is kept for a backward pass); geometry limits are the library's (tdvc_conv_pair_supported)"""
+    if TAPE is not None or x.f32 or x.C != 64:
+        return False
+    d = L.ConvPairDesc()
+    d.x = x.desc()
+    d.y = out.desc() if out is not None else x.desc()
+    d.res2 = res2.desc() if res2 is not None else L.FMapDesc()
+    d.w = d.bias = 1            # presence only; never dereferenced by the query
+    return bool(L.lib().tdvc_conv_pair_supported(C.byref(d)))
+
+
+def conv_pair(x: FM, pp: PackedConvPair, out: FM | None = None, act1=ACT_RELU, slope1=0.0, act2=ACT_NONE, slope2=0.0,
+              add_input=True, res2: FM | None = None) -> FM:
+    """y = act2(conv2(act1(conv1(x)))) [+ x] [+ res2] in one launch (`tdvc_conv_pair`)"""
+    if TAPE is not None:
+        raise L.TdvcHipError("conv_pair: inference only (the intermediate map is not kept for the backward pass)")
+    if out is None:
+        out = FM.empty(x.N, x.H, x.W, 64, device=x.t.device)
+    d = _pair_desc(x, pp, out, act1, slope1, act2, slope2, add_input, res2)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(L.lib().tdvc_conv_pair(C.byref(d), _stream()), "conv_pair")
+        e1.record()
+        fl = 2 * 2.0 * x.N * x.H * x.W * 64 * 64 * 9
+        PROFILE.append(dict(kernel="conv_pair", shape=f"2x(3x3 s1 64->64) @{x.H}x{x.W}", e0=e0, e1=e1, flops=fl, flops_real=fl,
+                            bytes=2.0 * x.N * x.H * x.W * 128))
+        return out
+    L.check(L.lib().tdvc_conv_pair(C.byref(d), _stream()), "conv_pair")
+    return out
+
+
 # ----------------------------------------------------------------------------- conv backward (training path)
 def act_backward(g: FM, y: FM, act, slope=0.0, res: FM | None = None, out: FM | None = None) -> FM:
     """g * act'(z); the sign of the pre-activation comes from the stored output y (minus its residual)"""
