@@ -4,11 +4,14 @@
 // LeakyReLU on both).  As two launches of conv_mfma_v10 the pair moves 5 maps through HBM (x, t, t, x, y: 640 B per pixel)
 // and each launch sits on the per-CU memory rate with its MFMA pipes half idle ("What bounds the 64-channel
 // 3x3 class").  Fusing through LDS needs both weight sets on chip (2 x 72 KB) next to the tiles: they do not fit in 160 KB
-// of LDS -- but they fit in REGISTERS once the work is split by output channel:
+// of LDS -- but they fit in REGISTERS once the work is split by output channel and by conv:
 //
-//   * 4 waves, one per SIMD (up to 512 VGPRs).  Wave w owns output channels [16w, 16w + 16) of BOTH convs and keeps their
-//     weights as v_mfma_f32_16x16x32_f16 A fragments: 2 convs x 9 taps x 2 chunks of 32 input channels = 36 fragments =
-//     144 VGPRs, loaded once per launch.  LDS holds activations only.
+//   * 8 waves, two per SIMD.  Waves 0-3 compute conv1, waves 4-7 conv2; wave w of a group owns output channels
+//     [16 (w & 3), +16) of its conv and keeps their weights as v_mfma_f32_16x16x32_f16 A fragments: 9 taps x 2 chunks of 32
+//     input channels = 18 fragments = 72 VGPRs, loaded once per launch.  LDS holds activations only.  A SIMD hosts one wave
+//     of each group: while one waits (LDS latency, a vector-memory instruction being accepted, the pack of a finished row)
+//     the other issues MFMAs.  (A first version with 4 waves holding both weight sets lost a third of its cycles to exactly
+//     those waits: a wave alone on its SIMD pays every one of them.)
 //   * row streaming.  A workgroup walks a strip of 30 output columns top to bottom.  Per step one input row (34 px, by
 //     LDS-DMA into a 16-row ring, 8 rows ahead) enters conv1: its B fragments (16 px x 32 channels) feed the three live
 //     rows of t (dy = 0, 1, 2: three rotating accumulator rows).  The finished row of t (32 px) is written to a small LDS
@@ -16,8 +19,8 @@
 //     row of y picks up the identity from the input ring, goes through an LDS staging row and leaves as full 128-byte
 //     lines.  No tile epilogue, no halo recompute in y (2 of 32 conv2 columns are waste: 97 % useful MFMAs); the vertical
 //     halo costs 5 extra steps per strip segment.
-//   * per step and wave: 72 MFMAs (1152 cycles), 24 ds_read_b128, ~40 other vector instructions, one s_barrier; per CU
-//     4.4 KB in + 3.8 KB out per step = 7 B per cycle at full MFMA rate -- under the ~10 B per cycle a CU can move.
+//   * per step and SIMD: 72 MFMAs (1152 cycles), 24 ds_read_b128, one s_barrier; per CU 4.4 KB in + 3.8 KB out per step =
+//     7 B per cycle at full MFMA rate -- under the ~10 B per cycle a CU can move.
 //   * HBM traffic of the pair: x once (+ 13 % column halo, mostly L2 hits) and y once: 256 B per pixel instead of 640.
 //
 // LDS image of a ring row: pixel-major, 128 B per pixel (64 channels), the 16-byte chunk c of pixel q stored at slot
@@ -34,7 +37,7 @@ constexpr int ROWB = 5120;                   // ring row: 40 pixel slots x 128 B
 constexpr int XRING = 16, TRING = 4, PF = 8; // input ring rows, t ring rows, DMA distance in rows
 constexpr int X0 = 0, T0 = XRING * ROWB, S0 = T0 + TRING * ROWB, SROW = 4096;
 constexpr int LDS_PAIR = S0 + 2 * SROW;      // 110 592 B
-constexpr int NTHR = 256;
+constexpr int NTHR = 512;
 
 struct PairParams {
   const half_t* x; long x_sn; int x_sp;
@@ -75,21 +78,19 @@ __device__ __forceinline__ half4 actk(half4 v, half4 sl) {
 // A1 / A2: activation after conv1 / conv2: 0 none, 1 ReLU, 2 max(v, v * slope) (LeakyReLU; slope 1 = none)
 template <int A1, int A2, bool ADDX, bool RES2, bool STAMP = false>
 __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, long long* stamps = nullptr, int stamp_cap = 0) {
-  long long st_busy = 0, st_vm = 0, st_bar = 0, st_a = 0, st_t0 = 0, st_n = 0;
+  long long st_busy = 0, st_vm = 0, st_bar = 0, st_n = 0;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wq = wave & 3;    // group 0: conv1, group 1: conv2; wq: the wave's block of 16 output channels
   const int r16 = lane & 15, kb = lane >> 4;
 
-  // ---- this wave's 16 output channels of both convs: 36 A fragments in registers for the whole launch
-  half8 wf[2][18];
+  // ---- this wave's 16 output channels of ITS conv: 18 A fragments in registers for the whole launch
+  half8 wf[18];
 #pragma unroll
-  for (int cv = 0; cv < 2; ++cv)
-#pragma unroll
-    for (int f = 0; f < 18; ++f) wf[cv][f] = *reinterpret_cast<const half8*>(p.w + ((((long)(cv * 4 + wave) * 18 + f) * 64 + lane) * 8));
-  const f32x4 bias1 = *reinterpret_cast<const f32x4*>(p.bias + 16 * wave + 4 * kb);       // C/D rows 4 kb + i of this wave's block
-  const f32x4 bias2 = *reinterpret_cast<const f32x4*>(p.bias + 64 + 16 * wave + 4 * kb);
+  for (int f = 0; f < 18; ++f) wf[f] = *reinterpret_cast<const half8*>(p.w + ((((long)(grp * 4 + wq) * 18 + f) * 64 + lane) * 8));
+  const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + 64 * grp + 16 * wq + 4 * kb);   // C/D rows 4 kb + i of this wave's block
 
   // ---- per-lane LDS offsets inside a ring row
   int foff[3][2];                              // B fragment (dx, channel chunk) of column block 0: pixel dx + (l & 15); block 1 sits
@@ -99,25 +100,26 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) foff[dx][kc] = q * 128 + (((4 * kc + kb) ^ sw) << 4);
   }
-  int doff[2], roff[2];                        // C/D layout (pixel l & 15, channels 16 w + 4 kb ..+3): t / staging write, identity read
+  int doff[2], roff[2];                        // C/D layout (pixel l & 15, channels 16 wq + 4 kb ..+3): t / staging write, identity read
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
-    const int q = 16 * cb + r16, c = 2 * wave + (kb >> 1);
+    const int q = 16 * cb + r16, c = 2 * wq + (kb >> 1);
     doff[cb] = q * 128 + ((c ^ ((q >> 1) & 7)) << 4) + 8 * (kb & 1);
     const int qx = q + 2;                      // output column yi sits at input pixel yi + 2
     roff[cb] = qx * 128 + ((c ^ ((qx >> 1) & 7)) << 4) + 8 * (kb & 1);
   }
-  // DMA items: piece j of a row covers pixels 8 j .. 8 j + 7 (lane: slot lane & 7 of pixel 8 j + (lane >> 3)).  Every step
-  // each wave sends piece `wave` of the row 8 steps ahead; piece 4 (pixels 32, 33) goes round the waves
+  // DMA items (conv1 waves): piece j of a row covers pixels 8 j .. 8 j + 7 (lane: slot lane & 7 of pixel 8 j + (lane >> 3)).
+  // Every step wave wq sends piece wq of the row 8 steps ahead; piece 4 (pixels 32, 33) goes round the four waves
   int soff_own, soff_4;
   {
-    const int q = 8 * wave + (lane >> 3), c = (lane & 7) ^ ((q >> 1) & 7);
+    const int q = 8 * wq + (lane >> 3), c = (lane & 7) ^ ((q >> 1) & 7);
     soff_own = q * p.x_sp + c * 8;
     const int q4 = 32 + (lane >> 3), c4 = (lane & 7) ^ ((q4 >> 1) & 7);
     soff_4 = q4 * p.x_sp + c4 * 8;
   }
-  // store item: thread = (output column tid >> 3, slot tid & 7)
-  const int s_yi = tid >> 3, s_c = (tid & 7) ^ ((s_yi >> 1) & 7);
+  // store item (conv2 waves): thread = (output column t >> 3, slot t & 7), t = tid - 256
+  const int s_t = tid & 255;
+  const int s_yi = s_t >> 3, s_c = (s_t & 7) ^ ((s_yi >> 1) & 7);
 
   // ---- XCD-aware job walk: workgroup b sits on XCD b % 8; an XCD takes a contiguous range of jobs (neighbouring strips
   // of one row segment share their column halo in that XCD's L2)
@@ -135,8 +137,8 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
   // activations as max(v, v * slope) in packed fp16 (slope 1: none, 0: ReLU), what the two-launch path computes
   const half_t hs1 = (half_t)p.slope1, hs2 = (half_t)p.slope2;
   const half4 sl1 = {hs1, hs1, hs1, hs1}, sl2 = {hs2, hs2, hs2, hs2};
-  f32x4 a1[3][2], a2[3][2];                    // rotating accumulator rows of t and y
-  half8 fbx[12], fbt[12];                      // B fragments of the current x row / t row
+  f32x4 acc[3][2];                             // rotating accumulator rows (of t in group 0, of y in group 1)
+  half8 fb[12];                                // B fragments of the row being consumed
   half8 r2v = {};
 
   for (int job = jfirst; job < jend; job += jstep) {
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
 
     bool col_own, col_4;                       // this lane's pixel of its pieces is inside the image (and one of the 34)
     {
-      const int q = 8 * wave + (lane >> 3), q4 = 32 + (lane >> 3);
+      const int q = 8 * wq + (lane >> 3), q4 = 32 + (lane >> 3);
       col_own = c0 - 2 + q >= 0 && c0 - 2 + q < p.W;
       col_4 = q4 < 34 && c0 - 2 + q4 < p.W;
     }
@@ -166,23 +168,23 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3)
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) { a1[s3][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; a2[s3][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int cb = 0; cb < 2; ++cb) acc[s3][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // x row ra - 2 + kk into ring slot kk & 15: this wave's piece, plus piece 4 when it is this wave's turn; returns the
-    // number of DMA instructions issued
+    // number of DMA instructions issued (conv1 waves only)
     auto issue_row = [&](int kk) __attribute__((always_inline)) -> int {
       const int row = ra - 2 + kk;
       const bool rowok = row >= 0 && row < p.H;
       const half_t* base = xn + ((long)row * p.W + (c0 - 2)) * p.x_sp;
       const unsigned dst = lds0 + X0 + (kk & (XRING - 1)) * ROWB;
-      glds16((rowok && col_own) ? base + soff_own : p.zeros, dst + wave * 1024);
-      if (wave == (kk & 3)) {
+      glds16((rowok && col_own) ? base + soff_own : p.zeros, dst + wq * 1024);
+      if (wq == (kk & 3)) {
         glds16((rowok && col_4) ? base + soff_4 : p.zeros, dst + 4 * 1024);
         return 2;
       }
       return 1;
     };
-    auto load_frags = [&](half8 (&fb)[12], unsigned rowbase) __attribute__((always_inline)) {
+    auto load_frags = [&](unsigned rowbase) __attribute__((always_inline)) {
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
@@ -192,27 +194,46 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
           for (int cb = 0; cb < 2; ++cb) fb[(cb * 3 + dx) * 2 + kc] = *reinterpret_cast<const half8*>(b0 + cb * 2048);
         }
     };
-
-    // ---- prologue: the first PF rows, two per wave; everything landed and visible before step 0
+    // the 36 MFMAs of one row: fragment (cb, dx, kc) x taps (dy, dx); SN / SM / SD: accumulator rows that start here (dy 0,
+    // bias as the C operand), continue (dy 1) and finish (dy 2, issued first so that the pack of the finished row overlaps the rest)
+    auto row_mfmas = [&](auto SNc, auto SMc, auto SDc, auto fin) __attribute__((always_inline)) {
+      constexpr int SN = decltype(SNc)::value, SM = decltype(SMc)::value, SD = decltype(SDc)::value;
 #pragma unroll
-    for (int kk = 0; kk < PF; ++kk)
-      if (kk <= rows + 3) issue_row(kk);
+      for (int dyo = 0; dyo < 3; ++dyo) {
+        const int dy = 2 - dyo;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+              const int slot = dy == 2 ? SD : (dy == 1 ? SM : SN);
+              const bool first = dy == 0 && dx == 0 && kc == 0;
+              acc[slot][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[(dy * 3 + dx) * 2 + kc], fb[(cb * 3 + dx) * 2 + kc],
+                                                                     first ? bias4 : acc[slot][cb], 0, 0, 0);
+            }
+        if (dy == 2) fin();
+      }
+    };
+
+    // ---- prologue: the first PF rows; everything landed and visible before step 0
+    if (grp == 0) {
+#pragma unroll
+      for (int kk = 0; kk < PF; ++kk)
+        if (kk <= rows + 3) issue_row(kk);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pair_barrier();
-    load_frags(fbx, X0);                       // x row of step 0
 
     const int K = rows + 6;
     unsigned hist = 0;                         // vector-memory operations this wave issued in each of the last four steps (one byte each)
     // Before a step's barrier: everything this wave sent more than four steps ago has landed (row k + 4 is read from step
-    // k + 3 on); the operations of the last four steps -- their number is tracked exactly -- may stay in flight.  Vector
-    // memory operations of a wave complete in order on this architecture (one counter for loads and stores).
+    // k + 4 on); the operations of the last four steps -- their number is tracked exactly -- may stay in flight.  Vector
+    // memory operations of a wave complete in order on this architecture (one counter for loads, stores and LDS-DMA).
     auto land_wait = [&](int nvm) __attribute__((always_inline)) {
       hist = (hist << 8) | (unsigned)nvm;
       const unsigned sum = (hist & 0xFFu) + ((hist >> 8) & 0xFFu) + ((hist >> 16) & 0xFFu) + (hist >> 24);
       switch (sum) {
-        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
         case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
         case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
         case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
@@ -221,47 +242,33 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
       }
     };
-    // One step.  FULL: the steady state (6 <= k <= rows + 2), where every part of the step is active: straight-line code
-    // but for the DMA turn, so that the scheduler can lay reads, packs and stores under the 72 MFMAs.
+    // One step k.  conv1 waves consume x row i = ra - 2 + k: t rows i + 1 (started), i, i - 1 (finished, into the t ring).
+    // conv2 waves consume t row i - 2 (finished last step): y rows i - 1 (started), i - 2, i - 3 (finished, + identity, into
+    // the staging row); the y row finished last step goes to memory.  FULL: the steady state (6 <= k <= rows + 2), where
+    // every part of the step is active: straight-line code per group.
     auto step = [&](auto PHc, auto FULLc, int k) __attribute__((always_inline)) {
       constexpr int PH = decltype(PHc)::value;       // k % 3: which accumulator row is new / mid / done
       constexpr bool FULL = decltype(FULLc)::value;
-      constexpr int NEW = (PH + 1) % 3, MID = PH, DONE = (PH + 2) % 3;
-      const int i = ra - 2 + k;                // x row of this step
-      long long t0 = 0, t1 = 0, t2 = 0, ta = 0;
+      using S0c = std::integral_constant<int, PH>;
+      using S1c = std::integral_constant<int, (PH + 1) % 3>;
+      using S2c = std::integral_constant<int, (PH + 2) % 3>;
+      const int i = ra - 2 + k;
+      long long t0 = 0, t1 = 0, t2 = 0;
       if constexpr (STAMP && FULL) t0 = clock64();       // lgkmcnt is 0 here (pair_barrier): the read costs nothing
-
-      // (b) the y row finished last step: out of the staging row now, to memory at the end of the step
-      int nvm = 0;
-      const int srow = ra + k - 6;
-      const bool have_row = FULL || (srow >= ra && srow < rb);
-      half8 yv = {};
-      if (have_row) yv = *reinterpret_cast<const half8*>(smem + S0 + ((k - 1) & 1) * SROW + tid * 16);
-      // (c) conv1: x row i feeds t rows i + 1 (dy 0, new), i (dy 1), i - 1 (dy 2, finished here)
-      const bool c1 = FULL || k <= rows + 3, c2 = FULL || (k >= 3 && k <= rows + 4);
-      if (c2) load_frags(fbt, T0 + ((k - 2) & (TRING - 1)) * ROWB);      // t row i - 2, written last step
-      if (c1) {
-#pragma unroll
-        for (int dyo = 0; dyo < 3; ++dyo) {
-          const int dy = 2 - dyo;              // the finishing row first: its pack / write overlaps the other MFMAs
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-            for (int kc = 0; kc < 2; ++kc)
-#pragma unroll
-              for (int cb = 0; cb < 2; ++cb) {
-                const int slot = dy == 2 ? DONE : (dy == 1 ? MID : NEW);
-                const bool first = dy == 0 && dx == 0 && kc == 0;
-                a1[slot][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][(dy * 3 + dx) * 2 + kc], fbx[(cb * 3 + dx) * 2 + kc],
-                                                                       first ? bias1 : a1[slot][cb], 0, 0, 0);
-              }
-          if (dy == 2) {                       // t row i - 1 -> fp16, activation, zero outside the image, into the t ring
+      if (grp == 0) {
+        // ---- conv1 wave: t row new = slot (PH + 1) % 3, mid = PH, done = (PH + 2) % 3
+        int nvm = 0;
+        if (FULL || k <= rows + 3) {
+          load_frags(X0 + (k & (XRING - 1)) * ROWB);
+          if (k + PF <= rows + 3 && !(p.experiment & 1)) nvm = issue_row(k + PF);
+          row_mfmas(S1c{}, S0c{}, S2c{}, [&]() __attribute__((always_inline)) {
+            // t row i - 1 -> fp16, activation, zero outside the image, into the t ring
             const int trow = i - 1;
             const unsigned rowm = (trow >= 0 && trow < p.H) ? 0xFFFFFFFFu : 0u;
             unsigned char* tb = smem + T0 + ((k - 1) & (TRING - 1)) * ROWB;
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
-              const f32x4 v = a1[DONE][cb];
+              const f32x4 v = acc[(PH + 2) % 3][cb];
               half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
               h = actk<A1>(h, sl1);
               typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -270,86 +277,54 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
               u[0] &= m; u[1] &= m;
               *reinterpret_cast<u32x2*>(tb + doff[cb]) = u;
             }
-          }
+          });
         }
-      }
-      if constexpr (FULL) {                    // 13 LDS reads (staging + t fragments) under the first 26 MFMAs of conv1
-#pragma unroll
-        for (int g = 0; g < 13; ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if constexpr (STAMP && FULL) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          t1 = clock64();
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (STAMP) { ta = clock64(); __builtin_amdgcn_sched_barrier(0); }
-      }
-      // (d) next step's x fragments (its row landed >= 3 steps ago), then conv2 on t row i - 2: y rows i - 1, i - 2, i - 3 (finished)
-      if (FULL || k + 1 <= rows + 3) load_frags(fbx, X0 + ((k + 1) & (XRING - 1)) * ROWB);
-      if (c2) {
-#pragma unroll
-        for (int dyo = 0; dyo < 3; ++dyo) {
-          const int dy = 2 - dyo;
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-            for (int kc = 0; kc < 2; ++kc)
-#pragma unroll
-              for (int cb = 0; cb < 2; ++cb) {
-                // y rows rotate one step behind t rows: y row (i - 2) + 1 - dy
-                const int slot = dy == 2 ? MID : (dy == 1 ? NEW : DONE);
-                const bool first = dy == 0 && dx == 0 && kc == 0;
-                a2[slot][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][(dy * 3 + dx) * 2 + kc], fbt[(cb * 3 + dx) * 2 + kc],
-                                                                       first ? bias2 : a2[slot][cb], 0, 0, 0);
-              }
-          if (dy == 2) {                       // y row i - 3 -> fp16, activation, + identity (x row i - 3 is still in the ring)
+        land_wait(nvm);
+      } else {
+        // ---- conv2 wave: y rows rotate one step behind t rows: new = (PH + 2) % 3, mid = (PH + 1) % 3, done = PH
+        const int srow = ra + k - 6;           // the y row finished last step: staging row -> memory
+        if (FULL || (srow >= ra && srow < rb)) {
+          half8 yv = *reinterpret_cast<const half8*>(smem + S0 + ((k - 1) & 1) * SROW + s_t * 16);
+          if constexpr (RES2) yv = yv + r2v;
+          half_t* dst = s_ok ? yn + ((long)srow * p.W + c0 + s_yi) * p.y_sp + s_c * 8 : p.dump + s_t * 8;
+          *reinterpret_cast<half8*>(dst) = yv;
+        }
+        if constexpr (RES2) {
+          const int nrow = srow + 1;
+          const bool ok = s_ok && (FULL || (nrow >= ra && nrow < rb));
+          const half_t* src = ok ? p.res2 + (long)n * p.r2_sn + ((long)nrow * p.W + c0 + s_yi) * p.r2_sp + s_c * 8 : p.zeros;
+          r2v = *reinterpret_cast<const half8*>(src);
+        }
+        if (FULL || (k >= 3 && k <= rows + 4)) {
+          load_frags(T0 + ((k - 2) & (TRING - 1)) * ROWB);       // t row i - 2, written last step
+          row_mfmas(S2c{}, S1c{}, S0c{}, [&]() __attribute__((always_inline)) {
+            // y row i - 3 -> fp16, activation, + identity (x row i - 3 is still in the ring), into the staging row
             unsigned char* sb = smem + S0 + (k & 1) * SROW;
             const unsigned char* xb = smem + X0 + ((k - 3) & (XRING - 1)) * ROWB;
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
-              const f32x4 v = a2[MID][cb];
+              const f32x4 v = acc[PH][cb];
               half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
               h = actk<A2>(h, sl2);
               if constexpr (ADDX) h = h + *reinterpret_cast<const half4*>(xb + roff[cb]);
               *reinterpret_cast<half4*>(sb + doff[cb]) = h;
             }
-          }
+          });
+        }
+        if constexpr (STAMP && FULL) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          t1 = clock64();
         }
       }
-      if constexpr (FULL) {                    // 12 x fragments + 2 identity reads under the first 28 MFMAs of conv2
-#pragma unroll
-        for (int g = 0; g < 14; ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-      }
-      // (e) vector memory at the END of the step, behind the last LDS reads: an LDS-DMA piece costs 100-185 cycles of issue
-      // among ds_reads and 25-60 in a gap without them (MI355X_MICROARCH.md, constants), and a wave alone on its SIMD pays
-      // every one of those cycles: the row PF steps ahead (this wave's piece), then the finished y row (lanes outside the
-      // strip write to a dump line: no branch)
-      if constexpr (FULL) __builtin_amdgcn_sched_barrier(0);
-      if (k + PF <= rows + 3 && !(p.experiment & 1)) nvm = issue_row(k + PF);
-      if (have_row) {
-        if constexpr (RES2) yv = yv + r2v;
-        half_t* dst = s_ok ? yn + ((long)srow * p.W + c0 + s_yi) * p.y_sp + s_c * 8 : p.dump + tid * 8;
-        *reinterpret_cast<half8*>(dst) = yv;
-        ++nvm;
-      }
-      if constexpr (RES2) {
-        const int nrow = srow + 1;
-        const bool ok = s_ok && (FULL || (nrow >= ra && nrow < rb));
-        const half_t* src = ok ? p.res2 + (long)n * p.r2_sn + ((long)nrow * p.W + c0 + s_yi) * p.r2_sp + s_c * 8 : p.zeros;
-        r2v = *reinterpret_cast<const half8*>(src);
-        ++nvm;
-      }
-      if constexpr (STAMP && FULL) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        t1 = clock64();
-      }
-      land_wait(nvm);
       if constexpr (STAMP && FULL) t2 = clock64();
       pair_barrier((p.experiment & 4) != 0);
       if constexpr (STAMP && FULL) {
         const long long t3 = clock64();
-        st_busy += t1 - t0; st_vm += t2 - t1; st_bar += t3 - t2; st_a += ta - t0; st_n += 1;
+        st_busy += t1 - t0; st_vm += t2 - t1; st_bar += t3 - t2; st_n += 1;
       }
     };
     using I0 = std::integral_constant<int, 0>;
@@ -373,11 +348,10 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
   }
   if constexpr (STAMP) {
     if (lane == 0 && (int)blockIdx.x < stamp_cap) {
-      long long* o = stamps + ((long)blockIdx.x * 4 + wave) * 8;
-      o[0] = st_busy; o[1] = st_vm; o[2] = st_bar; o[3] = st_a; o[4] = st_n;
+      long long* o = stamps + ((long)blockIdx.x * 8 + wave) * 8;
+      o[0] = st_busy; o[1] = st_vm; o[2] = st_bar; o[3] = 0; o[4] = st_n;
     }
   }
-  (void)st_t0;
 }
 
 }  // namespace

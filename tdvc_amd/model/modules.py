@@ -92,6 +92,11 @@ class Res_Block(nn.Module, PackCache):
         self.conv2 = nn.Conv2d(channels, channels, 3, 1, 1)
 
     def run(self, x: FM, out: FM | None = None, res2: FM | None = None) -> FM:
+        # inference: both convs in one launch, the intermediate map stays in LDS (tdvc_conv_pair); under the tape (training)
+        # and for shapes the fused kernel does not take, two launches
+        if self.conv1.in_channels == 64 and ops.conv_pair_supported(x, out, res2) and (out is None or out.desc().p != x.desc().p):
+            pp = self._pk("pair", lambda: ops.pack_conv_pair(self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias))
+            return ops.conv_pair(x, pp, out=out, act1=ACT_RELU, act2=ACT_NONE, add_input=True, res2=res2)
         t = ops.conv(x, pk_conv(self, "c1", self.conv1), act=ACT_RELU)
         return ops.conv(t, pk_conv(self, "c2", self.conv2), out=out, res=x, res2=res2)
 

@@ -29,7 +29,10 @@ def refresh_packed(model: torch.nn.Module) -> None:
         if hasattr(m, "refresh_packed"):
             m.refresh_packed()                       # GDN (effective gamma / beta), EntropyBottleneck (packed table)
             continue
-        pcs += [pc for pc in m.__dict__.get("_packed", {}).values() if isinstance(pc, ops.PackedConv)]
+        pk = m.__dict__.get("_packed", {})
+        pcs += [pc for pc in pk.values() if isinstance(pc, ops.PackedConv)]
+        for key in [k for k, v in pk.items() if isinstance(v, ops.PackedConvPair)]:
+            del pk[key]                              # inference-only fused form (Res_Block): rebuilt from the live weights on next use
     batch = model.__dict__.get("_pack_batch")
     if batch is None or [id(pc) for pc in batch.roots] != [id(pc) for pc in pcs]:
         batch = ops.PackBatch(pcs)                   # one launch for every conv layer (forward, dgrad and column forms)

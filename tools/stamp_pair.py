@@ -18,7 +18,7 @@ pp = ops.pack_conv_pair(w1, b1, w2, b1)
 for _ in range(5):
     ops.conv_pair(x, pp, out=y)
 torch.cuda.synchronize()
-buf = torch.zeros(256 * 4 * 8, dtype=torch.int64, device="cuda")
+buf = torch.zeros(256 * 8 * 8, dtype=torch.int64, device="cuda")
 for e in (0, 1, 2, 4, 7):
     ex(e)
     fn(buf.data_ptr(), 256)
@@ -26,11 +26,11 @@ for e in (0, 1, 2, 4, 7):
         ops.conv_pair(x, pp, out=y)
     torch.cuda.synchronize()
     fn(None, 0)
-    r = buf.view(256, 4, 8).double().cpu()
+    r = buf.view(256, 8, 8).double().cpu()
     n = r[:, :, 4].clamp(min=1)
     per = lambda j: (r[:, :, j] / n)
     tot = per(0) + per(1) + per(2)
-    print(f"experiment {e}: steps/wave {float(n.mean()):.0f}; cycles per step: total {float(tot.mean()):.0f} = busy {float(per(0).mean()):.0f} "
-          f"(conv1 phase {float(per(3).mean()):.0f}) + vmcnt wait {float(per(1).mean()):.0f} + barrier {float(per(2).mean()):.0f}; "
-          f"per wave busy {[round(float(per(0)[:, w].mean())) for w in range(4)]} barrier {[round(float(per(2)[:, w].mean())) for w in range(4)]}", flush=True)
+    print(f"experiment {e}: steps/wave {float(n.mean()):.0f}; cycles per step: total {float(tot.mean()):.0f}; per wave (0-3 conv1, 4-7 conv2) "
+          f"busy {[round(float(per(0)[:, w].mean())) for w in range(8)]} vmcnt wait {[round(float(per(1)[:, w].mean())) for w in range(8)]} "
+          f"barrier {[round(float(per(2)[:, w].mean())) for w in range(8)]}", flush=True)
 ex(0)
