@@ -24,8 +24,13 @@
 //   * HBM traffic of the pair: x once (+ 13 % column halo, mostly L2 hits) and y once: 256 B per pixel instead of 640.
 //
 // LDS image of a ring row: pixel-major, 128 B per pixel (64 channels), the 16-byte chunk c of pixel q stored at slot
-// c ^ ((q >> 1) & 7): the ds_read_b128 of a B fragment (lane = pixel l & 15, channel block l >> 4) is then conflict-free on
-// the 4 x 16-lane groups of that instruction.  For the DMA-written input rows the XOR sits on the SOURCE address.
+// c ^ G[(q >> 1) & 7], G = {0, 1, 2, 4, 5, 6, 2, 6}.  A B fragment is read by ds_read_b128 with lane = (pixel p0 + (l & 15),
+// channel block l >> 4); the instruction is served in four groups of 16 lanes, each of which holds the 16 pixels once, the
+// middle eight with the neighbouring channel block (c ^ 1).  The plain (q >> 1) & 7 is conflict-free only for p0 = 0 mod 4
+// (the dx = 0 tap); the taps dx = 1, 2 shift the window and two pairs of lanes meet in one 16-byte bank slot (rocprofv3:
+// SQ_LDS_BANK_CONFLICT = 40 % of SQ_LDS_IDX_ACTIVE).  G is one of the 720 tables (exhaustive search) that keep all three
+// windows conflict-free; it costs the few 8-byte C/D-layout accesses (t / staging writes, identity read) a second pass.
+// For the DMA-written input rows the XOR sits on the SOURCE address.
 #include <type_traits>
 
 #include "conv_common.h"
@@ -52,6 +57,9 @@ struct PairParams {
   float slope1, slope2;     // max(v, v * slope): 1 = none, 0 = ReLU, else LeakyReLU
   int experiment;           // timing diagnostics (tdvc_debug_set_pair_experiment): 1 no DMA after the prologue, 2 stores to the dump line, 4 no barrier
 };
+
+// swizzle term of pixel q of a ring row (see the LDS image note at the top)
+__device__ __forceinline__ int swz(int q) { return (int)((0x62654210u >> (4 * ((q >> 1) & 7))) & 7u); }
 
 __device__ __forceinline__ void glds16(const half_t* gsrc, unsigned lds_dst) {
   unsigned keep;
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
   int foff[3][2];                              // B fragment (dx, channel chunk) of column block 0: pixel dx + (l & 15); block 1 sits
 #pragma unroll                                 // 16 pixels = 2048 B further (16 pixels do not change the swizzle term)
   for (int dx = 0; dx < 3; ++dx) {
-    const int q = dx + r16, sw = (q >> 1) & 7;
+    const int q = dx + r16, sw = swz(q);
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) foff[dx][kc] = q * 128 + (((4 * kc + kb) ^ sw) << 4);
   }
@@ -104,22 +112,22 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     const int q = 16 * cb + r16, c = 2 * wq + (kb >> 1);
-    doff[cb] = q * 128 + ((c ^ ((q >> 1) & 7)) << 4) + 8 * (kb & 1);
+    doff[cb] = q * 128 + ((c ^ swz(q)) << 4) + 8 * (kb & 1);
     const int qx = q + 2;                      // output column yi sits at input pixel yi + 2
-    roff[cb] = qx * 128 + ((c ^ ((qx >> 1) & 7)) << 4) + 8 * (kb & 1);
+    roff[cb] = qx * 128 + ((c ^ swz(qx)) << 4) + 8 * (kb & 1);
   }
   // DMA items (conv1 waves): piece j of a row covers pixels 8 j .. 8 j + 7 (lane: slot lane & 7 of pixel 8 j + (lane >> 3)).
   // Every step wave wq sends piece wq of the row 8 steps ahead; piece 4 (pixels 32, 33) goes round the four waves
   int soff_own, soff_4;
   {
-    const int q = 8 * wq + (lane >> 3), c = (lane & 7) ^ ((q >> 1) & 7);
+    const int q = 8 * wq + (lane >> 3), c = (lane & 7) ^ swz(q);
     soff_own = q * p.x_sp + c * 8;
-    const int q4 = 32 + (lane >> 3), c4 = (lane & 7) ^ ((q4 >> 1) & 7);
+    const int q4 = 32 + (lane >> 3), c4 = (lane & 7) ^ swz(q4);
     soff_4 = q4 * p.x_sp + c4 * 8;
   }
   // store item (conv2 waves): thread = (output column t >> 3, slot t & 7), t = tid - 256
   const int s_t = tid & 255;
-  const int s_yi = s_t >> 3, s_c = (s_t & 7) ^ ((s_yi >> 1) & 7);
+  const int s_yi = s_t >> 3, s_c = (s_t & 7) ^ swz(s_yi);
 
   // ---- XCD-aware job walk: workgroup b sits on XCD b % 8; an XCD takes a contiguous range of jobs (neighbouring strips
   // of one row segment share their column halo in that XCD's L2)
