@@ -59,6 +59,8 @@ CASES = [
     (1, 128, 90, "lrelu", "lrelu", False, False, False),    # LeakyReLU pair without identity
     (4, 48, 192, "none", "relu", False, True, False),       # batch of slices, activation only after conv2
     (1, 272, 480, "relu", "none", True, False, False),      # a real geometry of the model (quarter resolution)
+    (5, 16, 1920, "relu", "none", True, False, False),      # 320 jobs on 256 workgroups: several jobs per workgroup, uneven XCD ranges
+    (1, 33, 250, "lrelu", "none", True, True, False),       # odd everything: 9 strips (last 10 px), segments of 17 + 16 rows
 ]
 
 
