@@ -293,6 +293,9 @@ class Bottleneck3D(nn.Module):
         self.conv3 = nn.Conv3d(64, 64, (1, 3, 3), padding=(0, 1, 1))
 
 
+LOOPFILTER_PAIR = True          # A/B switch (tools/ab_infer.py): layer1.conv1 + spatial_conv3d as one tdvc_conv_pair launch
+
+
 class LoopFilter(nn.Module, PackCache):
     """`main/model/pnet.py:266-317`: multi-frame feature fusion.  The (B,64,T=4,H,W) tensor of the
     reference is one (B,H,W,256) buffer whose four 64-channel slices are the frames, so the
@@ -327,9 +330,18 @@ class LoopFilter(nn.Module, PackCache):
         self._slices("c1", self.conv1, xt, a, **lr)
         l1 = self.layer1
         bf = FM.empty(B, H, W, 256, device=dev)
-        self._slices("b1", l1.conv1, a, bf, **lr)
         s = FM.empty(B, H, W, 256, device=dev)
-        self._slices("bs", l1.spatial_conv3d, bf, s)
+        if LOOPFILTER_PAIR and ops.conv_pair_supported(a.as_slices(0, 4, 64), s.as_slices(0, 4, 64)):
+            # inference: layer1.conv1 (LeakyReLU) and layer1.spatial_conv3d in one launch per batch item, their intermediate
+            # map stays in LDS (`bf` is then only the block's output buffer below)
+            pp = self._pk("pair_b1_bs", lambda: ops.pack_conv_pair(l1.conv1.weight.view(64, 64, 3, 3), l1.conv1.bias,
+                                                                    l1.spatial_conv3d.weight.view(64, 64, 3, 3), l1.spatial_conv3d.bias))
+            for b in range(B):
+                ops.conv_pair(a.as_slices(b, 4, 64), pp, out=s.as_slices(b, 4, 64), act1=ACT_LRELU, slope1=0.1, act2=ACT_NONE,
+                              add_input=False)
+        else:
+            self._slices("b1", l1.conv1, a, bf, **lr)
+            self._slices("bs", l1.spatial_conv3d, bf, s)
         tm = ops.conv(s.ch(0, 192), pk_conv(self, "bt", l1.temporal_conv3d))
         if ops.TAPE is not None:
             s = ops.clone(s)          # `s` itself is the temporal conv's input: keep it for the backward pass
