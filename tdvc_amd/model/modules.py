@@ -225,8 +225,13 @@ class OffsetGen(nn.Module, PackCache):
             c = cats[i]
             o1 = ops.conv(c, pk_conv(self, "c11" + lv, self.offset_conv11[lv]), **lr)
             if i == 3:
-                o1 = ops.conv(o1, pk_conv(self, "c11_1" + lv, self.offset_conv11_1[lv]), **lr)
-                off = ops.conv(o1, pk_conv(self, "c12" + lv, self.offset_conv12[lv]), **lr)
+                if ops.conv_pair_supported(o1):            # inference: offset_conv11_1 + offset_conv12 (both LeakyReLU) in one launch
+                    c1_, c2_ = self.offset_conv11_1[lv], self.offset_conv12[lv]
+                    pp = self._pk("pair_l3", lambda: ops.pack_conv_pair(c1_.weight, c1_.bias, c2_.weight, c2_.bias))
+                    off = ops.conv_pair(o1, pp, act1=ACT_LRELU, slope1=0.1, act2=ACT_LRELU, slope2=0.1, add_input=False)
+                else:
+                    o1 = ops.conv(o1, pk_conv(self, "c11_1" + lv, self.offset_conv11_1[lv]), **lr)
+                    off = ops.conv(o1, pk_conv(self, "c12" + lv, self.offset_conv12[lv]), **lr)
             else:
                 ops.conv(o1, pk_conv(self, "c11_1" + lv, self.offset_conv11_1[lv]), out=up_o1.ch(64, 64), **lr)
                 off = ops.conv(up_o1, pk_conv(self, "ff" + lv, self.feat_fusion[lv]), **lr)
