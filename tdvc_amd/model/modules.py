@@ -328,11 +328,23 @@ class LoopFilter(nn.Module, PackCache):
         dev = xt.t.device
         lr = dict(act=ACT_LRELU, slope=0.1)
         p01, p02 = pk_conv(self, "c01", self.conv01), pk_conv(self, "c02", self.conv02)
+        a = FM.empty(B, H, W, 256, device=dev)
+        fuse = LOOPFILTER_PAIR and ops.conv_pair_supported(a.as_slices(0, 4, 64).batch(0, 3))
+        if fuse:
+            # inference: conv02 (no activation) + conv1 (LeakyReLU) of the three reference slices in one launch -- nothing else
+            # reads conv02's output; slice 3 (prediction1, already in xt) takes conv1 alone
+            pp = self._pk("pair_c02_c1", lambda: ops.pack_conv_pair(self.conv02.weight, self.conv02.bias,
+                                                                     self.conv1.weight.view(64, 64, 3, 3), self.conv1.bias))
+            pc1 = pk_conv(self, "c1", self.conv1)
         for b in range(B):
             t = ops.conv(refs8.batch(4 * b + 1, 3), p01, **lr)                 # (3,H,W,64)
-            ops.conv(t, p02, out=xt.as_slices(b, 4, 64).batch(0, 3))
-        a = FM.empty(B, H, W, 256, device=dev)
-        self._slices("c1", self.conv1, xt, a, **lr)
+            if fuse:
+                ops.conv_pair(t, pp, out=a.as_slices(b, 4, 64).batch(0, 3), act1=ACT_NONE, act2=ACT_LRELU, slope2=0.1, add_input=False)
+                ops.conv(xt.as_slices(b, 4, 64).batch(3, 1), pc1, out=a.as_slices(b, 4, 64).batch(3, 1), **lr)
+            else:
+                ops.conv(t, p02, out=xt.as_slices(b, 4, 64).batch(0, 3))
+        if not fuse:
+            self._slices("c1", self.conv1, xt, a, **lr)
         l1 = self.layer1
         bf = FM.empty(B, H, W, 256, device=dev)
         s = FM.empty(B, H, W, 256, device=dev)
