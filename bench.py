@@ -233,8 +233,8 @@ def roofline_leg(runner):
             fn = lambda: ops.conv(x, pc, out=y, act=ops.ACT_RELU)
             flop = 2.0 * P * L["cout"] * L["cin"] * 9
             alg = 2.0 * P * (L["cin"] + L["cout"])
-        _time_launches(fn, 5)                              # the first timed loop of a process runs slow (clock ramp)
-        ms = _time_launches(fn)
+        _time_launches(fn, 10)                             # the first timed loop of a process runs slow (clock ramp)
+        ms = sorted(_time_launches(fn) for _ in range(3))[1]        # median of three loops of 20 back-to-back launches
         ach = flop / (ms * 1e-3) / 1e12
         traffic = pmc_traffic_bytes(L["pmc"])
         return {"kernel": kname, "launch": f"{L['what']} on {ran} ({flop / 1e9:.1f} GFLOP, {alg / 1e6:.1f} MB algorithmic)",
