@@ -102,6 +102,36 @@ def test_conv_pair_vs_reference(N, H, W, act1, act2, add, with_res2, views, repo
         assert torch.equal(y.t, first), "launch-to-launch mismatch"
 
 
+def test_conv_pair_random_shapes(report):
+    """seeded sweep over geometries, activations and residual options against the same pair as two tdvc_conv2d launches
+    (strips / segments / multi-job walks are all functions of N, H, W)"""
+    import random
+    ops = _ops()
+    rng = random.Random(2024)
+    A = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU}
+    w1, b1, w2, b2 = _weights(41)
+    pp = ops.pack_conv_pair(w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda())
+    pc1, pc2 = ops.pack_conv(w1, b1, stride=1, pad=1), ops.pack_conv(w2, b2, stride=1, pad=1)
+    worst = 0.0
+    for it in range(14):
+        N = rng.choice([1, 1, 2, 3])
+        H = rng.randint(16, 150)
+        W = max(rng.randint(31, 420), -(-8192 // H))
+        act1, act2 = rng.choice(["relu", "lrelu", "none"]), rng.choice(["none", "lrelu", "relu"])
+        add, with_r2 = rng.random() < 0.6, rng.random() < 0.4
+        x = to_fm(rnd16(randn(N, 64, H, W, seed=100 + it)), ops)
+        r2 = to_fm(rnd16(randn(N, 64, H, W, seed=200 + it)), ops) if with_r2 else None
+        assert ops.conv_pair_supported(x, None, r2), (N, H, W)
+        y = ops.conv_pair(x, pp, act1=A[act1], slope1=0.2, act2=A[act2], slope2=0.05, add_input=add, res2=r2)
+        t = ops.conv(x, pc1, act=A[act1], slope=0.2)
+        res = [m for m in ((x if add else None), r2) if m is not None]
+        y2 = ops.conv(t, pc2, act=A[act2], slope=0.05, res=res[0] if res else None, res2=res[1] if len(res) > 1 else None)
+        d = float((fm_to_cpu(y).double() - fm_to_cpu(y2).double()).abs().max())
+        worst = max(worst, d)
+        assert d <= 2e-2, (it, N, H, W, act1, act2, add, with_r2, d)
+    report(f"conv_pair random sweep (14 shapes): max |pair - two launches| = {worst:.3e}")
+
+
 def test_conv_pair_refuses_training_and_bad_shapes():
     ops = _ops()
     x = ops.FM.empty(1, 96, 96, 64, device="cuda")
