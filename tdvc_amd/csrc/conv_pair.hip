@@ -19,7 +19,7 @@
 //     row of y picks up the identity from the input ring, goes through an LDS staging row and leaves as full 128-byte
 //     lines.  No tile epilogue, no halo recompute in y (2 of 32 conv2 columns are waste: 97 % useful MFMAs); the vertical
 //     halo costs 5 extra steps per strip segment.
-//   * per step and SIMD: 72 MFMAs (1152 cycles), 24 ds_read_b128, one s_barrier per two steps; per CU 4.4 KB in + 3.8 KB out per step =
+//   * per step and SIMD: 72 MFMAs (1152 cycles), 24 ds_read_b128, one s_barrier per BI = 4 steps; per CU 4.4 KB in + 3.8 KB out per step =
 //     7 B per cycle at full MFMA rate -- under the ~10 B per cycle a CU can move.
 //   * HBM traffic of the pair: x once (+ 13 % column halo, mostly L2 hits) and y once: 256 B per pixel instead of 640.
 //
@@ -39,9 +39,11 @@ namespace {
 
 constexpr int PW = 30;                       // output columns per strip
 constexpr int ROWB = 5120;                   // ring row: 40 pixel slots x 128 B = 5 DMA pieces of 1 KB (34 used)
-constexpr int XRING = 16, TRING = 4, PF = 8; // input ring rows, t ring rows, DMA distance in rows
+constexpr int BI = 4;                        // row steps per workgroup barrier (a power of two)
+constexpr int XRING = 16, TRING = 2 * BI, PF = 8; // input ring rows, t ring rows (BI being written + BI being read), DMA distance in rows
 constexpr int X0 = 0, T0 = XRING * ROWB, S0 = T0 + TRING * ROWB, SROW = 4096;
-constexpr int LDS_PAIR = S0 + 4 * SROW;      // 118 784 B
+constexpr int LDS_PAIR = S0 + 2 * BI * SROW;  // staging ring like the t ring; BI = 4: 155 648 B
+static_assert(LDS_PAIR <= 160 * 1024 && BI + 2 + PF <= XRING - 1 && PF >= BI + 4, "rings");
 constexpr int NTHR = 512;
 
 struct PairParams {
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pair_barrier();
 
-    const int K = (rows + 8 + 1) & ~1;         // row steps; the barrier closes every second one, so an even number
+    const int K = (rows + 4 + 2 * BI + BI - 1) & ~(BI - 1);      // row steps, a whole number of barrier intervals
     unsigned hist = 0;                         // vector-memory operations this wave issued in each of the last four steps (one byte each)
     // Before a step's barrier: everything this wave sent more than four steps ago has landed (row k + 4 is read from step
     // k + 4 on); the operations of the last four steps -- their number is tracked exactly -- may stay in flight.  Vector
@@ -251,12 +253,12 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
       }
     };
     // One row step k.  conv1 waves consume x row i = ra - 2 + k: t rows i + 1 (started), i, i - 1 (finished, into the t ring).
-    // conv2 waves consume t row i - 3: y rows i - 2 (started), i - 3, i - 4 (finished, + identity, into a staging row); the y row
-    // finished two row steps ago goes to memory.  The workgroup barrier closes every SECOND row step: each group reads only
-    // rows that were finished before the last barrier (hence t row i - 3 and the staging row of step k - 2) and the 4-row t
-    // and staging rings hold exactly the two rows being written and the two being read (- 2 % time: after a barrier both
-    // waves of a SIMD wait for their LDS reads together; in the middle of an interval they have drifted apart).
-    // FULL: the steady state (8 <= k <= rows + 2), where every part is active: straight-line code per group.
+    // conv2 waves consume t row i - 1 - BI: y rows i - BI (started), i - 1 - BI, i - 2 - BI (finished, + identity, into a staging
+    // row); the y row finished BI row steps ago goes to memory.  The workgroup barrier closes every BI-th row step: each group
+    // reads only rows that were finished before the last barrier, and the 2 BI-row t and staging rings hold exactly the BI
+    // rows being written and the BI being read.  Between barriers the waves run free: the step time follows the average wave,
+    // not the slowest one of every step (stamps without the barrier: 16 % fewer cycles per step).
+    // FULL: the steady state (4 + 2 BI <= k <= rows + 2), where every part is active: straight-line code per group.
     auto step = [&](auto PHc, auto FULLc, int k) __attribute__((always_inline)) {
       constexpr int PH = decltype(PHc)::value;       // k % 3: which accumulator row is new / mid / done
       constexpr bool FULL = decltype(FULLc)::value;
@@ -297,9 +299,9 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
         land_wait(nvm);
       } else {
         // ---- conv2 wave: new = (PH + 2) % 3, mid = (PH + 1) % 3, done = PH
-        const int srow = ra + k - 8;           // the y row finished two row steps ago (before the last barrier): staging row -> memory
+        const int srow = ra + k - 4 - 2 * BI;  // the y row finished BI row steps ago (before the last barrier): staging row -> memory
         if (FULL || (srow >= ra && srow < rb)) {
-          half8 yv = *reinterpret_cast<const half8*>(smem + S0 + ((k - 2) & 3) * SROW + s_t * 16);
+          half8 yv = *reinterpret_cast<const half8*>(smem + S0 + ((k - BI) & (2 * BI - 1)) * SROW + s_t * 16);
           if constexpr (RES2) yv = yv + r2v;
           half_t* dst = s_ok ? yn + ((long)srow * p.W + c0 + s_yi) * p.y_sp + s_c * 8 : p.dump + s_t * 8;
           *reinterpret_cast<half8*>(dst) = yv;
@@ -310,12 +312,12 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
           const half_t* src = ok ? p.res2 + (long)n * p.r2_sn + ((long)nrow * p.W + c0 + s_yi) * p.r2_sp + s_c * 8 : p.zeros;
           r2v = *reinterpret_cast<const half8*>(src);
         }
-        if (FULL || (k >= 4 && k <= rows + 5)) {
-          load_frags(T0 + ((k - 3) & (TRING - 1)) * ROWB);       // t row i - 3, finished before the last barrier
+        if (FULL || (k >= BI + 2 && k <= rows + 3 + BI)) {
+          load_frags(T0 + ((k - 1 - BI) & (TRING - 1)) * ROWB);       // t row i - 1 - BI, finished before the last barrier
           row_mfmas(S2c{}, S1c{}, S0c{}, [&]() __attribute__((always_inline)) {
-            // y row i - 4 -> fp16, activation, + identity (x row i - 4 is still in the ring), into the staging row
-            unsigned char* sb = smem + S0 + (k & 3) * SROW;
-            const unsigned char* xb = smem + X0 + ((k - 4) & (XRING - 1)) * ROWB;
+            // y row i - 2 - BI -> fp16, activation, + identity (that x row is still in the ring), into the staging row
+            unsigned char* sb = smem + S0 + (k & (2 * BI - 1)) * SROW;
+            const unsigned char* xb = smem + X0 + ((k - 2 - BI) & (XRING - 1)) * ROWB;
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
               const f32x4 v = acc[PH][cb];
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
         }
       }
       if constexpr (STAMP && FULL) t2 = clock64();
-      pair_barrier(!(k & 1) || (p.experiment & 4) != 0);     // one barrier per TWO row steps
+      pair_barrier((k & (BI - 1)) != BI - 1 || (p.experiment & 4) != 0);     // one barrier per BI row steps
       if constexpr (STAMP && FULL) {
         const long long t3 = clock64();
         st_busy += t1 - t0; st_vm += t2 - t1; st_bar += t3 - t2; st_n += 1;
@@ -348,8 +350,9 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
         if (k + 2 < kend) step(I2{}, std::false_type{}, k + 2);
       }
     };
-    edge_steps(0, 9);
-    int k = 9;
+    constexpr int KF = ((4 + 2 * BI + 2) / 3) * 3;      // first steady-state step: a multiple of 3 (accumulator rotation) >= 4 + 2 BI
+    edge_steps(0, KF);
+    int k = KF;
     for (; k + 2 <= rows + 2; k += 3) {
       step(I0{}, std::true_type{}, k);
       step(I1{}, std::true_type{}, k + 1);
