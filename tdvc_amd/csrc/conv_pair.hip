@@ -19,7 +19,7 @@
 //     row of y picks up the identity from the input ring, goes through an LDS staging row and leaves as full 128-byte
 //     lines.  No tile epilogue, no halo recompute in y (2 of 32 conv2 columns are waste: 97 % useful MFMAs); the vertical
 //     halo costs 5 extra steps per strip segment.
-//   * per step and SIMD: 72 MFMAs (1152 cycles), 24 ds_read_b128, one s_barrier per BI = 4 steps; per CU 4.4 KB in + 3.8 KB out per step =
+//   * per step and SIMD: 72 MFMAs (1152 cycles), 24 ds_read_b128, one s_barrier per BI = 2 steps; per CU 4.4 KB in + 3.8 KB out per step =
 //     7 B per cycle at full MFMA rate -- under the ~10 B per cycle a CU can move.
 //   * HBM traffic of the pair: x once (+ 13 % column halo, mostly L2 hits) and y once: 256 B per pixel instead of 640.
 //
@@ -39,11 +39,17 @@ namespace {
 
 constexpr int PW = 30;                       // output columns per strip
 constexpr int ROWB = 5120;                   // ring row: 40 pixel slots x 128 B = 5 DMA pieces of 1 KB (34 used)
-constexpr int BI = 4;                        // row steps per workgroup barrier (a power of two)
+// Row steps per workgroup barrier (a power of two).  Between two barriers the waves drift apart by up to BI - 1 steps, and
+// every ring must cover that skew: the t and staging rings hold 2 BI rows (BI being written + BI being read); the input ring
+// must hold the row being loaded (PF ahead of the fastest conv1 wave), the identity row of the slowest conv2 wave (BI + 2
+// behind its own step, BI - 1 steps of skew further back) and everything between: PF + 2 BI + 2 <= XRING.  BI = 4 was
+// 2.5 % faster but needs 18 input rows (it ran with 16 and lost a race about once in a hundred launches: the DMA of row
+// k + 8 landed on the row whose identity a conv2 wave three steps behind had not read yet).
+constexpr int BI = 2;
 constexpr int XRING = 16, TRING = 2 * BI, PF = 8; // input ring rows, t ring rows (BI being written + BI being read), DMA distance in rows
 constexpr int X0 = 0, T0 = XRING * ROWB, S0 = T0 + TRING * ROWB, SROW = 4096;
 constexpr int LDS_PAIR = S0 + 2 * BI * SROW;  // staging ring like the t ring; BI = 4: 155 648 B
-static_assert(LDS_PAIR <= 160 * 1024 && BI + 2 + PF <= XRING - 1 && PF >= BI + 4, "rings");
+static_assert(LDS_PAIR <= 160 * 1024 && PF + 2 * BI + 2 <= XRING && PF >= 4 + BI, "rings");
 constexpr int NTHR = 512;
 
 struct PairParams {

@@ -132,6 +132,23 @@ def test_conv_pair_random_shapes(report):
     report(f"conv_pair random sweep (14 shapes): max |pair - two launches| = {worst:.3e}")
 
 
+@pytest.mark.parametrize("N,H,W,r2", [(1, 33, 250, True), (4, 48, 192, True), (1, 100, 131, False)])
+def test_conv_pair_launches_are_reproducible(N, H, W, r2, report):
+    """150 launches of the shapes most exposed to a synchronisation hole (short row segments, a ragged last strip, the second
+    residual slowing the conv2 waves) must all equal the first: with one barrier per FOUR row steps and a 16-row input ring
+    the 33x250 case lost a write-after-read race on every few launches (tools/stress_pair.py; conv_pair.hip, `BI`)"""
+    ops = _ops()
+    w1, b1, w2, b2 = _weights(51)
+    pp = ops.pack_conv_pair(w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda())
+    x = to_fm(rnd16(randn(N, 64, H, W, seed=52)), ops)
+    res2 = to_fm(rnd16(randn(N, 64, H, W, seed=53)), ops) if r2 else None
+    kw = dict(act1=ops.ACT_LRELU, slope1=0.1, res2=res2)
+    first = ops.conv_pair(x, pp, **kw).t.clone()
+    bad = sum(0 if torch.equal(ops.conv_pair(x, pp, **kw).t, first) else 1 for _ in range(150))
+    report(f"conv_pair {N}x{H}x{W} res2={r2}: {bad} of 150 launches differ from the first")
+    assert bad == 0
+
+
 def test_conv_pair_refuses_training_and_bad_shapes():
     ops = _ops()
     x = ops.FM.empty(1, 96, 96, 64, device="cuda")

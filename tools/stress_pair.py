@@ -1,0 +1,27 @@
+"""repeat the conv_pair cases most exposed to synchronisation holes (short segments, ragged strips, second residual) and
+compare every launch with the first: python tools/stress_pair.py [reps]"""
+import sys
+import torch
+sys.path.insert(0, "/root/repo")
+from tdvc_amd import ops
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+torch.manual_seed(3)
+w = [torch.randn(64, 64, 3, 3, device="cuda") * 0.05 for _ in range(2)]
+b = [torch.randn(64, device="cuda") * 0.1 for _ in range(2)]
+pp = ops.pack_conv_pair(w[0], b[0], w[1], b[1])
+bad = 0
+for (N, H, W, r2) in ((1, 33, 250, True), (1, 100, 131, False), (2, 64, 160, True), (5, 16, 1920, False), (1, 272, 480, True), (4, 48, 192, True)):
+    x = ops.FM(torch.randn(N, H, W, 64, device="cuda").half())
+    res2 = ops.FM(torch.randn(N, H, W, 64, device="cuda").half()) if r2 else None
+    y0 = ops.conv_pair(x, pp, res2=res2, act1=ops.ACT_LRELU, slope1=0.1)
+    ref = y0.t.clone()
+    n_bad = 0
+    for _ in range(reps):
+        y = ops.conv_pair(x, pp, res2=res2, act1=ops.ACT_LRELU, slope1=0.1)
+        if not torch.equal(y.t, ref):
+            n_bad += 1
+    print(f"{N}x{H}x{W} res2={r2}: {n_bad} of {reps} launches differ from the first", flush=True)
+    bad += n_bad
+print("TOTAL MISMATCHES", bad)
+sys.exit(1 if bad else 0)
