@@ -82,6 +82,10 @@ typedef struct {
 int tdvc_abi_version(void);
 /* Human-readable description of the last error on this thread (never NULL). */
 const char* tdvc_last_error(void);
+/* Creates the current device's scratch pages (a zero page the halo DMA reads, a dump page masked stores go to).  The
+ * launchers create them on first use, synchronously: call this once per device before capturing launches into a graph.
+ * Thread-safe; one allocation per device for the life of the process. */
+int tdvc_prepare_device(void);
 /* Name of the kernel the last tdvc_conv2d call on this thread dispatched to ("conv_mfma_v7", "conv_mfma<4,2,1>",
  * ...; "" before the first call).  Diagnostic for profiles and benchmarks; never NULL. */
 const char* tdvc_last_conv_kernel(void);
@@ -128,7 +132,9 @@ int64_t tdvc_conv_pair_packed_bytes(void);
 /* host-side packing of the two fp32 OIHW [64][64][3][3] weights into per-wave v_mfma_f32_16x16x32_f16 A fragments
  * (layout in tdvc_amd/csrc/conv_pair.hip); dst: tdvc_conv_pair_packed_bytes() bytes of host memory, caller uploads */
 int tdvc_pack_conv_pair_weights(const float* w1_oihw, const float* w2_oihw, uint16_t* dst);
-/* 1 when tdvc_conv_pair takes this descriptor (geometry / size limits), 0: run the two convs through tdvc_conv2d */
+/* 1 when tdvc_conv_pair takes this descriptor (geometry / size limits, LeakyReLU slopes in [0, 1], x and y not overlapping
+ * except as disjoint channel windows of one buffer), 0: run the two convs through tdvc_conv2d.  y.p == x.p asks about the
+ * geometry only (output not allocated yet); tdvc_conv_pair itself refuses that descriptor. */
 int tdvc_conv_pair_supported(const tdvc_conv_pair_desc* d);
 int tdvc_conv_pair(const tdvc_conv_pair_desc* d, void* stream);
 
@@ -433,6 +439,14 @@ int tdvc_dcn_columns(const tdvc_fmap* x, const tdvc_fmap* om, int groups, const 
 int64_t tdvc_dcn_col2im_work_floats(int N, int H, int W, int groups);
 int tdvc_dcn_col2im(const tdvc_fmap* x, const tdvc_fmap* om, const tdvc_fmap* dcol, int groups, float* dx32, const tdvc_fmap* dom,
                     float* work, int64_t work_floats, void* stream);
+/* Run-to-run reproducible form (tdvc_amd.ops.DETERMINISTIC; the reproducible training run of the parity tests): samples
+ * displaced out of their tile's window are recorded instead of added with float atomics -- far_keys[i] (unique: target
+ * (n, y, x, group) << 27 | source pixel * 36 + tap * 4 + corner), far_vals[i][8]; *far_count (device, zeroed by the caller)
+ * counts every such sample, records beyond far_cap are dropped (the caller checks the count).  The caller sorts the keys
+ * (any stable device sort; `order` = the permutation) and tdvc_dcn_far_apply adds each target's records in key order. */
+int tdvc_dcn_col2im_det(const tdvc_fmap* x, const tdvc_fmap* om, const tdvc_fmap* dcol, int groups, float* dx32, const tdvc_fmap* dom,
+                        float* work, int64_t work_floats, int64_t* far_keys, float* far_vals, int32_t* far_count, int32_t far_cap, void* stream);
+int tdvc_dcn_far_apply(const int64_t* keys_sorted, const int64_t* order, const float* far_vals, int32_t count, float* dx32, void* stream);
 
 /* ---------------------------------------------------------------- quality metrics (evaluation loop)
  * One level of MS-SSIM as main/model/ms_ssim_torch.py:33-83 computes it on a float32 NCHW pair: valid separable

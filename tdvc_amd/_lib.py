@@ -52,6 +52,7 @@ SIGNATURES = {
     "tdvc_abi_version": (_i, []),
     "tdvc_last_error": (C.c_char_p, []),
     "tdvc_last_conv_kernel": (C.c_char_p, []),
+    "tdvc_prepare_device": (_i, []),
     "tdvc_conv_plan": (_i, [_i, _i, _i, _i]),
     "tdvc_conv_packed_bytes": (_i64, [_i, _i, _i, _i]),
     "tdvc_pack_conv_weights": (_i, [_P, _i, _i, _i, _i, _i, _i, _P, _P, _i, _P]),
@@ -89,6 +90,8 @@ SIGNATURES = {
     "tdvc_avgpool2_pad_f32": (_i, [_P, _i64, _i, _i, _P, _P]),
     "tdvc_dcn_col2im_work_floats": (_i64, [_i, _i, _i, _i]),
     "tdvc_dcn_col2im": (_i, [_FM, _FM, _FM, _i, _P, _FM, _P, _i64, _P]),
+    "tdvc_dcn_col2im_det": (_i, [_FM, _FM, _FM, _i, _P, _FM, _P, _i64, _P, _P, _P, _i, _P]),
+    "tdvc_dcn_far_apply": (_i, [_P, _P, _P, _i, _P, _P]),
     "tdvc_conv_wgrad_work_floats": (_i64, [_i] * 6),
     "tdvc_conv_wgrad": (_i, [_FM, _FM] + [_i] * 6 + [_P] * 5 + [_i, _f, _P, _P, _i64, _P]),
     "tdvc_conv_wgrad_bias": (_i, [_FM, _FM] + [_i] * 6 + [_P] * 5 + [_i, _f, _P, _P, _P, _P, _i64, _P]),

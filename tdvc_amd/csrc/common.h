@@ -15,6 +15,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void tdvc_set_error(const char* fmt, ...);
+// per-device scratch (lib.cpp): >= 4 KB of zeros nobody writes, >= 16 KB dump page nobody reads; 0 or a HIP error code
+int tdvc_scratch_pages(const void** zeros, void** dump);
 
 #define TDVC_CHECK(cond, ...)            \
   do {                                   \

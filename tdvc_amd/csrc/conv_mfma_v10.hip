@@ -379,18 +379,14 @@ bool conv_v10_eligible(const tdvc_conv_desc* d, const ConvParams& p, int Ho, int
 }
 
 int launch_conv_v10(const ConvParams& p, int cout_blocks, int N, hipStream_t st) {
-  static half_t* zeros = nullptr;
-  if (!zeros) {
-    hipError_t err = hipMalloc(reinterpret_cast<void**>(&zeros), 256);
-    if (err == hipSuccess) err = hipMemset(zeros, 0, 256);
-    if (err != hipSuccess) { zeros = nullptr; tdvc_set_error("conv v10: zero page allocation failed: %s", hipGetErrorString(err)); return (int)err; }
-  }
+  const void* zeros = nullptr;
+  if (const int zrc = tdvc_scratch_pages(&zeros, nullptr)) return zrc;
   ConvParams q = p;
   q.tiles_x = (p.Wo + TW10 - 1) / TW10;
   const int tiles_y = (p.Ho + TH10 - 1) / TH10;
   V10Extra e;
   e.ntiles = q.tiles_x * tiles_y;
-  e.zeros = zeros;
+  e.zeros = reinterpret_cast<const half_t*>(zeros);
   q.slope = convk::conv_simple_slope(p);
   int gx = 256 / (cout_blocks * N);
   if (gx < 1) gx = 1;

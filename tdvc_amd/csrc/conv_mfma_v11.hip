@@ -324,24 +324,26 @@ bool conv_v11_eligible(const tdvc_conv_desc* d, const ConvParams& p, int Ho, int
   if (off || !g_v11_enabled) return false;
   bool taps33 = d->ntaps == 9 && d->kh == 3 && d->kw == 3 && d->pad == 1;
   for (int t = 0; taps33 && t < 9; ++t) taps33 = d->tap_dy[t] == t / 3 && d->tap_dx[t] == t % 3;
-  return taps33 && d->ck == 32 && d->stride == 1 && d->cout >= 64 && (d->cout % 64) == 0 && (d->x.C % 32) == 0 && d->x.C >= min_cin && !d->s2d &&
+  // The counted `vmcnt(8)` at the top of a stage assumes that EVERY wave issued its 8 epilogue stores: a narrower output view
+  // (y.C at or below cout - 32, or cout / 4 - 32 for the sub-pixel store) would leave whole waves without stores and their
+  // weight DMA pieces in flight across the barrier -- such launches go to the stage-pipelined kernel instead.
+  // A wave covers 32 consecutive packed rows (cout % 64 == 0 here; sub-pixel store: inside one sub-pixel, cq % 32 == 0): it
+  // stores as soon as its first 8-channel chunk is inside the view.
+  const bool all_waves_store = d->y.C > (p.out_mode == TDVC_OUT_SHUFFLE2 ? (d->cout >> 2) : d->cout) - 32;
+  return taps33 && all_waves_store && d->ck == 32 && d->stride == 1 && d->cout >= 64 && (d->cout % 64) == 0 && (d->x.C % 32) == 0 && d->x.C >= min_cin && !d->s2d &&
          !d->square_input && (long)Ho * Wo >= 8192 &&
          (convk::conv_is_lean(p) || (convk::conv_is_simple(p) && !p.gdn && p.out_mode == TDVC_OUT_SHUFFLE2 && ((d->cout >> 2) % 32) == 0));
 }
 
 int launch_conv_v11(const ConvParams& p, int cout_blocks, int N, hipStream_t st) {
-  static half_t* zeros = nullptr;
-  if (!zeros) {
-    hipError_t err = hipMalloc(reinterpret_cast<void**>(&zeros), 256);
-    if (err == hipSuccess) err = hipMemset(zeros, 0, 256);
-    if (err != hipSuccess) { zeros = nullptr; tdvc_set_error("conv v11: zero page allocation failed: %s", hipGetErrorString(err)); return (int)err; }
-  }
+  const void* zeros = nullptr;
+  if (const int zrc = tdvc_scratch_pages(&zeros, nullptr)) return zrc;
   ConvParams q = p;
   q.tiles_x = (p.Wo + TW11 - 1) / TW11;
   const int tiles_y = (p.Ho + TH11 - 1) / TH11;
   V11Extra e;
   e.ntiles = q.tiles_x * tiles_y;
-  e.zeros = zeros;
+  e.zeros = reinterpret_cast<const half_t*>(zeros);
   e.experiment = g_v11_experiment;
   q.slope = convk::conv_simple_slope(p);
   int gx = 256 / (cout_blocks * N);

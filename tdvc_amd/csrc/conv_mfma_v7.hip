@@ -239,23 +239,22 @@ bool conv_v7_eligible(const tdvc_conv_desc* d, const ConvParams& p, int Ho, int 
   if (off) return false;
   bool taps33 = d->ntaps == 9 && d->kh == 3 && d->kw == 3 && d->pad == 1;
   for (int t = 0; taps33 && t < 9; ++t) taps33 = d->tap_dy[t] == t / 3 && d->tap_dx[t] == t % 3;
-  return taps33 && d->ck == 32 && d->stride == 1 && d->cout >= 64 && (d->x.C == 32 || d->x.C == 64) && !d->s2d &&
+  // the counted vmcnt(8) of a full tile assumes every wave stored (see conv_v11_eligible); here a wave covers the 64 packed
+  // rows of its cout block (sub-pixel store: inside one sub-pixel, cq % 64 == 0 by conv_is_simple)
+  const bool all_waves_store = d->y.C > (p.out_mode == TDVC_OUT_SHUFFLE2 ? (d->cout >> 2) - 64 : ((d->cout + 63) / 64 - 1) * 64);
+  return taps33 && all_waves_store && d->ck == 32 && d->stride == 1 && d->cout >= 64 && (d->x.C == 32 || d->x.C == 64) && !d->s2d &&
          !d->square_input && (long)Ho * Wo >= 8192 && convk::conv_is_simple(p);
 }
 
 int launch_conv_v7(const ConvParams& p, int cout_blocks, int N, hipStream_t st) {
-  static half_t* zeros = nullptr;
-  if (!zeros) {
-    hipError_t err = hipMalloc(reinterpret_cast<void**>(&zeros), 256);
-    if (err == hipSuccess) err = hipMemset(zeros, 0, 256);
-    if (err != hipSuccess) { zeros = nullptr; tdvc_set_error("conv v7: zero page allocation failed: %s", hipGetErrorString(err)); return (int)err; }
-  }
+  const void* zeros = nullptr;
+  if (const int zrc = tdvc_scratch_pages(&zeros, nullptr)) return zrc;
   ConvParams q = p;
   q.tiles_x = (p.Wo + TW7 - 1) / TW7;
   const int tiles_y = (p.Ho + TH7 - 1) / TH7;
   V7Extra e;
   e.ntiles = q.tiles_x * tiles_y;
-  e.zeros = zeros;
+  e.zeros = reinterpret_cast<const half_t*>(zeros);
   q.slope = convk::conv_simple_slope(p);
   int gx = 256 / (cout_blocks * N);
   if (gx < 1) gx = 1;

@@ -39,17 +39,43 @@ namespace {
 
 constexpr int PW = 30;                       // output columns per strip
 constexpr int ROWB = 5120;                   // ring row: 40 pixel slots x 128 B = 5 DMA pieces of 1 KB (34 used)
-// Row steps per workgroup barrier (a power of two).  Between two barriers the waves drift apart by up to BI - 1 steps, and
-// every ring must cover that skew: the t and staging rings hold 2 BI rows (BI being written + BI being read); the input ring
-// must hold the row being loaded (PF ahead of the fastest conv1 wave), the identity row of the slowest conv2 wave (BI + 2
-// behind its own step, BI - 1 steps of skew further back) and everything between: PF + 2 BI + 2 <= XRING.  BI = 4 was
-// 2.5 % faster but needs 18 input rows (it ran with 16 and lost a race about once in a hundred launches: the DMA of row
-// k + 8 landed on the row whose identity a conv2 wave three steps behind had not read yet).
-constexpr int BI = 2;
-constexpr int XRING = 16, TRING = 2 * BI, PF = 8; // input ring rows, t ring rows (BI being written + BI being read), DMA distance in rows
+// ---- synchronisation geometry.  A "step" k consumes one input row; a workgroup barrier closes every BI-th step, so between
+// two barriers any two waves are at most BI - 1 steps apart and always in the same barrier interval.  Every ring / landing
+// condition the kernel relies on is one named inequality below (row numbers in step units: "row r" = what step r consumes).
+constexpr int BI = 2;                        // row steps per workgroup barrier (a power of two)
+constexpr int XRING = 16;                    // input ring rows (power of two)
+constexpr int PF = 8;                        // the DMA of row k + PF is ISSUED in step k (conv1 waves)
+constexpr int HD = 4;                        // land_wait() after step s lets the DMA issued in steps s - HD + 1 .. s stay in flight
+constexpr int VM_PER_STEP = 2;               // most vector-memory instructions a conv1 wave issues per step (its piece + piece 4)
+constexpr int TRING = 2 * BI;                // t ring rows: conv1 writes row k - 1 in step k, conv2 reads row k - 1 - BI
+constexpr int SRING = 2 * BI;                // staging ring rows: conv2 writes row k in step k, stores row k - BI
+constexpr int T_LAG = 1 + BI;                // conv2 consumes t row r in step r + T_LAG (r is written in step r + 1)
+constexpr int ID_LAG = 2 + BI;               // conv2 reads the identity (x ring row k - ID_LAG) in step k
 constexpr int X0 = 0, T0 = XRING * ROWB, S0 = T0 + TRING * ROWB, SROW = 4096;
-constexpr int LDS_PAIR = S0 + 2 * BI * SROW;  // staging ring like the t ring; BI = 4: 155 648 B
-static_assert(LDS_PAIR <= 160 * 1024 && PF + 2 * BI + 2 <= XRING && PF >= 4 + BI, "rings");
+constexpr int LDS_PAIR = S0 + SRING * SROW;
+// (1) input ring, write-after-read.  The DMA issued in step k by the fastest conv1 wave overwrites row k + PF - XRING; the
+//     slowest wave of the interval is at step >= k - (BI - 1) and its oldest x-ring read is the identity row ID_LAG behind it:
+//     k + PF - XRING < k - (BI - 1) - ID_LAG.
+static_assert(PF - XRING < -(BI - 1) - ID_LAG, "input ring: a DMA would land on a row whose identity a conv2 wave BI - 1 steps behind has not read (needs PF + 2 BI + 2 <= XRING)");
+// (2) input ring, read-after-write (landing).  A wave's own pieces of row r (issued in step r - PF) are only known to have
+//     landed after its land_wait() of a step s >= r - PF + HD, and other waves' pieces only after a barrier behind that wait.
+//     The last barrier before step r closes a step kb >= r - BI: r - PF + HD <= r - BI.
+static_assert(PF >= HD + BI, "landing: row r must be past land_wait()'s history window before the last barrier in front of step r");
+// (3) the counted wait: at most HD steps x VM_PER_STEP instructions are left in flight, land_wait() has a case for every
+//     sum in [HD, HD * VM_PER_STEP] and falls back to vmcnt(0) otherwise; the hardware counter holds 63.
+static_assert(HD == 4 && VM_PER_STEP == 2 && HD * VM_PER_STEP <= 63, "land_wait(): the switch covers sums 4..8 of a 4-step history");
+// (4) t ring.  In one barrier interval [m BI, m BI + BI - 1] conv1 writes rows m BI - 1 .. m BI + BI - 2 and conv2 reads rows
+//     m BI - T_LAG .. m BI + BI - 1 - T_LAG: 2 BI consecutive rows when T_LAG = 1 + BI, which must not alias; a row is read BI
+//     steps after it was written and overwritten BI steps after it was read: a barrier lies between either pair.
+static_assert(T_LAG == 1 + BI && TRING >= 2 * BI && (TRING & (TRING - 1)) == 0, "t ring: BI rows being written + BI rows being read");
+// (5) staging ring: row k written in step k (each conv2 wave its 16 channels), stored by thread items in step k + BI,
+//     overwritten in step k + SRING: a barrier between write and store needs the BI lag, one between store and overwrite SRING - BI >= BI.
+static_assert(SRING >= 2 * BI && (SRING & (SRING - 1)) == 0, "staging ring: BI rows being written + BI rows being stored");
+// (6) the identity row k - ID_LAG was consumed by conv1 in step k - ID_LAG (so it has landed) and is still in the ring by (1).
+static_assert(ID_LAG >= 1 && ID_LAG <= XRING - PF - BI, "identity row inside the input ring");
+static_assert((BI & (BI - 1)) == 0 && (XRING & (XRING - 1)) == 0 && LDS_PAIR <= 160 * 1024, "power-of-two rings inside 160 KB of LDS");
+// BI = 4 (2.5 % faster in isolation) fails (1)+(2) with HD = 4: PF >= 8 and PF <= 6.  With HD = 2 / PF = 6 both hold and the
+// rings take 155 648 B; measured gain < 1 % on the frame's four-slice launches, so BI = 2 ships.
 constexpr int NTHR = 512;
 
 struct PairParams {
@@ -307,7 +333,7 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
         // ---- conv2 wave: new = (PH + 2) % 3, mid = (PH + 1) % 3, done = PH
         const int srow = ra + k - 4 - 2 * BI;  // the y row finished BI row steps ago (before the last barrier): staging row -> memory
         if (FULL || (srow >= ra && srow < rb)) {
-          half8 yv = *reinterpret_cast<const half8*>(smem + S0 + ((k - BI) & (2 * BI - 1)) * SROW + s_t * 16);
+          half8 yv = *reinterpret_cast<const half8*>(smem + S0 + ((k - BI) & (SRING - 1)) * SROW + s_t * 16);
           if constexpr (RES2) yv = yv + r2v;
           half_t* dst = s_ok ? yn + ((long)srow * p.W + c0 + s_yi) * p.y_sp + s_c * 8 : p.dump + s_t * 8;
           *reinterpret_cast<half8*>(dst) = yv;
@@ -319,11 +345,11 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
           r2v = *reinterpret_cast<const half8*>(src);
         }
         if (FULL || (k >= BI + 2 && k <= rows + 3 + BI)) {
-          load_frags(T0 + ((k - 1 - BI) & (TRING - 1)) * ROWB);       // t row i - 1 - BI, finished before the last barrier
+          load_frags(T0 + ((k - T_LAG) & (TRING - 1)) * ROWB);       // t row i - 1 - BI, finished before the last barrier
           row_mfmas(S2c{}, S1c{}, S0c{}, [&]() __attribute__((always_inline)) {
             // y row i - 2 - BI -> fp16, activation, + identity (that x row is still in the ring), into the staging row
-            unsigned char* sb = smem + S0 + (k & (2 * BI - 1)) * SROW;
-            const unsigned char* xb = smem + X0 + ((k - 2 - BI) & (XRING - 1)) * ROWB;
+            unsigned char* sb = smem + S0 + (k & (SRING - 1)) * SROW;
+            const unsigned char* xb = smem + X0 + ((k - ID_LAG) & (XRING - 1)) * ROWB;
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
               const f32x4 v = acc[PH][cb];
@@ -408,13 +434,25 @@ extern "C" int tdvc_pack_conv_pair_weights(const float* w1_oihw, const float* w2
   return TDVC_OK;
 }
 
+// x rows are re-read as halo after neighbouring y rows were written: x and y may share a buffer only as disjoint channel
+// windows of the same pixels (cat buffers); any other overlap of the two address ranges is refused
+static bool pair_buffers_ok(const tdvc_fmap& x, const tdvc_fmap& y) {
+  const uintptr_t xa = (uintptr_t)x.p, ya = (uintptr_t)y.p;
+  const uintptr_t xe = xa + 2 * ((uintptr_t)(x.N - 1) * x.sn + ((uintptr_t)x.H * x.W - 1) * x.sp + 64);
+  const uintptr_t ye = ya + 2 * ((uintptr_t)(y.N - 1) * y.sn + ((uintptr_t)y.H * y.W - 1) * y.sp + 64);
+  if (!(xa < ye && ya < xe)) return true;
+  const uintptr_t gap = xa > ya ? xa - ya : ya - xa;
+  return x.sp == y.sp && x.sn == y.sn && gap >= 128 && gap + 128 <= 2 * (uintptr_t)x.sp;
+}
+
 extern "C" int tdvc_conv_pair_supported(const tdvc_conv_pair_desc* d) {
   static const bool off = getenv("TDVC_NO_CONV_PAIR") != nullptr;
   if (off || !g_pair_enabled || !d) return 0;
   const tdvc_fmap &x = d->x, &y = d->y;
   const bool ok = fmap_ok16(x) && fmap_ok16(y) && x.C == 64 && y.C == 64 && x.N == y.N && x.H == y.H && x.W == y.W && d->w && d->bias &&
                   (!d->res2.p || (fmap_ok16(d->res2) && d->res2.C == 64 && d->res2.N == x.N && d->res2.H == x.H && d->res2.W == x.W)) &&
-                  (long)x.H * x.W >= 8192 && x.H >= 16;
+                  (long)x.H * x.W >= 8192 && x.H >= 16 && (x.p == y.p /* geometry-only query: y not allocated yet */ || pair_buffers_ok(x, y)) &&
+                  (d->act1 != TDVC_ACT_LRELU || (d->slope1 >= 0.f && d->slope1 <= 1.f)) && (d->act2 != TDVC_ACT_LRELU || (d->slope2 >= 0.f && d->slope2 <= 1.f));
   return ok ? 1 : 0;
 }
 
@@ -425,25 +463,24 @@ extern "C" int tdvc_conv_pair(const tdvc_conv_pair_desc* d, void* stream) {
   TDVC_CHECK(d->w && d->bias, "tdvc_conv_pair: weights / bias missing");
   TDVC_CHECK(!d->res2.p || (fmap_ok16(d->res2) && d->res2.C == 64 && d->res2.N == d->x.N && d->res2.H == d->x.H && d->res2.W == d->x.W),
              "tdvc_conv_pair: res2 must be an fp16 map of the output geometry");
-  TDVC_CHECK(d->x.p != d->y.p, "tdvc_conv_pair: in-place operation is not supported (rows of x are re-read as halo)");
+  TDVC_CHECK(pair_buffers_ok(d->x, d->y), "tdvc_conv_pair: x and y overlap (in-place operation is not supported: rows of x are re-read as halo)");
+  TDVC_CHECK((d->act1 != TDVC_ACT_LRELU || (d->slope1 >= 0.f && d->slope1 <= 1.f)) && (d->act2 != TDVC_ACT_LRELU || (d->slope2 >= 0.f && d->slope2 <= 1.f)),
+             "tdvc_conv_pair: LeakyReLU is computed as max(v, v * slope) and needs 0 <= slope <= 1");
   auto slope_of = [](int act, float slope) { return act == TDVC_ACT_NONE ? 1.f : (act == TDVC_ACT_RELU ? 0.f : slope); };
   TDVC_CHECK((d->act1 == TDVC_ACT_NONE || d->act1 == TDVC_ACT_RELU || d->act1 == TDVC_ACT_LRELU) &&
              (d->act2 == TDVC_ACT_NONE || d->act2 == TDVC_ACT_RELU || d->act2 == TDVC_ACT_LRELU), "tdvc_conv_pair: activations are none / ReLU / LeakyReLU");
-  static half_t* zeros = nullptr;        // [0, 256): zeros; [256, 256 + 4096): dump lines
-  if (!zeros) {
-    hipError_t err = hipMalloc(reinterpret_cast<void**>(&zeros), 256 + 4096);
-    if (err == hipSuccess) err = hipMemset(zeros, 0, 256 + 4096);
-    if (err != hipSuccess) { zeros = nullptr; tdvc_set_error("tdvc_conv_pair: zero page allocation failed: %s", hipGetErrorString(err)); return (int)err; }
-  }
+  const void* zeros = nullptr;
+  void* dump = nullptr;
+  if (const int zrc = tdvc_scratch_pages(&zeros, &dump)) return zrc;
   PairParams p;
   p.x = reinterpret_cast<const half_t*>(d->x.p); p.x_sn = d->x.sn; p.x_sp = d->x.sp;
   p.y = reinterpret_cast<half_t*>(d->y.p); p.y_sn = d->y.sn; p.y_sp = d->y.sp;
   p.res2 = reinterpret_cast<const half_t*>(d->res2.p); p.r2_sn = d->res2.p ? d->res2.sn : 0; p.r2_sp = d->res2.p ? d->res2.sp : 0;
   p.w = reinterpret_cast<const half_t*>(d->w);
   p.bias = d->bias;
-  p.zeros = zeros;
+  p.zeros = reinterpret_cast<const half_t*>(zeros);
   p.experiment = g_pair_experiment;
-  p.dump = zeros + 128;
+  p.dump = reinterpret_cast<half_t*>(dump);
   p.N = d->x.N; p.H = d->x.H; p.W = d->x.W;
   p.slope1 = slope_of(d->act1, d->slope1);
   p.slope2 = slope_of(d->act2, d->slope2);

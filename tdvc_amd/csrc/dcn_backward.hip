@@ -164,6 +164,13 @@ struct DcnBw {
   float* dx32;
   float* wbuf;               // [N*G][tiles][32*32*8] scatter windows
   int G;
+  // deterministic mode (tdvc_dcn_col2im_det): samples displaced out of the window are RECORDED instead of added with float
+  // atomics: key = (target (n, y, x, g) << 27) | (source pixel * 36 + tap * 4 + corner), 8 values; the caller sorts the keys and
+  // tdvc_dcn_far_apply adds each target's records in key order
+  long long* far_key;
+  float* far_val;
+  int* far_count;
+  int far_cap;
 };
 
 __device__ __forceinline__ void dcn_geom(const DcnBw& p, long i, int& n, long& pix, int& g, int& t, float& h_im, float& w_im, float& mask) {
@@ -305,9 +312,20 @@ __global__ __launch_bounds__(64) void dcn_col2im_kernel(const DcnBw p) {
       }
       asm volatile("" ::: "memory");
       if (active && !inwin) {
-        float* dg = dxn + off_px * (8 * p.G);
+        if (p.far_key) {
+          const int slot = atomicAdd(p.far_count, 1);          // slot order is arbitrary: the records are sorted by key afterwards
+          if (slot < p.far_cap) {
+            const long long tgt_id = (((long long)n * H * W + off_px) * p.G + g);
+            p.far_key[slot] = (tgt_id << 27) | (long long)(pix * 36 + t * 4 + ci);
+            float4* fv = reinterpret_cast<float4*>(p.far_val + (long)slot * 8);
+            fv[0] = float4{a[0], a[1], a[2], a[3]};
+            fv[1] = float4{a[4], a[5], a[6], a[7]};
+          }
+        } else {
+          float* dg = dxn + off_px * (8 * p.G);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) unsafeAtomicAdd(dg + j, a[j]);
+          for (int j = 0; j < 8; ++j) unsafeAtomicAdd(dg + j, a[j]);
+        }
       }
     };
     corner(0, hl, wl, (1.f - lh) * (1.f - lw), -(1.f - lw), -(1.f - lh));
@@ -362,6 +380,24 @@ __global__ void dcn_window_gather_kernel(const DcnBw p, int tiles_x, int tiles_y
   u.x += a.x; u.y += a.y; u.z += a.z; u.w += a.w;
   v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
   d[0] = u; d[1] = v;
+}
+
+// deterministic mode: record `order[i]` is the i-th in key order; the thread at the first record of a target adds that
+// target's records in key order (unique keys: a fixed order), then into dx32 (no other thread owns this target)
+__global__ void dcn_far_apply_kernel(const long long* keys_sorted, const long long* order, const float* vals, int count, float* dx32) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const long long tgt = keys_sorted[i] >> 27;
+  if (i > 0 && (keys_sorted[i - 1] >> 27) == tgt) return;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int j = i; j < count && (keys_sorted[j] >> 27) == tgt; ++j) {
+    const float* v = vals + order[j] * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s[c] += v[c];
+  }
+  float* d = dx32 + tgt * 8;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) d[c] += s[c];
 }
 
 inline dim3 g1(long n) { return dim3((unsigned)((n + 255) / 256)); }
@@ -421,6 +457,7 @@ extern "C" int tdvc_dcn_columns(const tdvc_fmap* x, const tdvc_fmap* om, int gro
   DcnBw p;
   p.wbuf = nullptr;
   p.x = to_dev(*x); p.om = to_dev(*om); p.col = to_dev(*col); p.dom = null_fmap(); p.dx32 = nullptr; p.G = groups;
+  p.far_key = nullptr; p.far_val = nullptr; p.far_count = nullptr; p.far_cap = 0;
   const long total = (long)x->N * x->H * x->W * groups * 9;
   hipLaunchKernelGGL(dcn_columns_kernel, g1(total), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, total);
   return tdvc_launch_status("tdvc_dcn_columns");
@@ -431,14 +468,39 @@ extern "C" int64_t tdvc_dcn_col2im_work_floats(int N, int H, int W, int groups) 
   return (int64_t)N * groups * ((W + C2I_T - 1) / C2I_T) * ((H + C2I_T - 1) / C2I_T) * (C2I_W * C2I_W * 8);
 }
 
+static int dcn_col2im_impl(const tdvc_fmap* x, const tdvc_fmap* om, const tdvc_fmap* dcol, int groups, float* dx32, const tdvc_fmap* dom,
+                           float* work, int64_t work_floats, long long* far_key, float* far_val, int* far_count, int far_cap, void* stream);
+
 extern "C" int tdvc_dcn_col2im(const tdvc_fmap* x, const tdvc_fmap* om, const tdvc_fmap* dcol, int groups, float* dx32, const tdvc_fmap* dom,
                                float* work, int64_t work_floats, void* stream) {
+  return dcn_col2im_impl(x, om, dcol, groups, dx32, dom, work, work_floats, nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int tdvc_dcn_col2im_det(const tdvc_fmap* x, const tdvc_fmap* om, const tdvc_fmap* dcol, int groups, float* dx32, const tdvc_fmap* dom,
+                                   float* work, int64_t work_floats, int64_t* far_keys, float* far_vals, int32_t* far_count, int32_t far_cap,
+                                   void* stream) {
+  TDVC_CHECK(far_keys && far_vals && far_count && far_cap >= 1 && (reinterpret_cast<uintptr_t>(far_vals) & 15) == 0, "tdvc_dcn_col2im_det: record buffers missing or unaligned");
+  TDVC_CHECK(x && (long)x->H * x->W * 36 < (1L << 27) && (long)x->N * x->H * x->W * groups < (1L << 36), "tdvc_dcn_col2im_det: map too large for the 27 + 36 bit record key");
+  return dcn_col2im_impl(x, om, dcol, groups, dx32, dom, work, work_floats, reinterpret_cast<long long*>(far_keys), far_vals, far_count, far_cap, stream);
+}
+
+extern "C" int tdvc_dcn_far_apply(const int64_t* keys_sorted, const int64_t* order, const float* far_vals, int32_t count, float* dx32, void* stream) {
+  TDVC_CHECK(keys_sorted && order && far_vals && dx32 && count >= 0, "tdvc_dcn_far_apply: bad arguments");
+  if (count == 0) return TDVC_OK;
+  hipLaunchKernelGGL(dcn_far_apply_kernel, g1(count), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const long long*>(keys_sorted),
+                     reinterpret_cast<const long long*>(order), far_vals, count, dx32);
+  return tdvc_launch_status("tdvc_dcn_far_apply");
+}
+
+static int dcn_col2im_impl(const tdvc_fmap* x, const tdvc_fmap* om, const tdvc_fmap* dcol, int groups, float* dx32, const tdvc_fmap* dom,
+                           float* work, int64_t work_floats, long long* far_key, float* far_val, int* far_count, int far_cap, void* stream) {
   TDVC_CHECK(x && om && dcol && dx32 && dom && work && dcn_bw_ok(*x, *om, *dcol, groups) && fmap_ok16(*dom) && dom->C >= 27 * groups && dom->N == x->N &&
                  dom->H == x->H && dom->W == x->W, "tdvc_dcn_col2im: bad arguments");
   TDVC_CHECK(work_floats >= tdvc_dcn_col2im_work_floats(x->N, x->H, x->W, groups) && (reinterpret_cast<uintptr_t>(work) & 15) == 0 &&
                  (reinterpret_cast<uintptr_t>(dx32) & 15) == 0, "tdvc_dcn_col2im: workspace too small or unaligned");
   DcnBw p;
   p.x = to_dev(*x); p.om = to_dev(*om); p.col = to_dev(*dcol); p.dom = to_dev(*dom); p.dx32 = dx32; p.wbuf = work; p.G = groups;
+  p.far_key = far_key; p.far_val = far_val; p.far_count = far_count; p.far_cap = far_cap;
   const int tiles_x = (x->W + C2I_T - 1) / C2I_T, tiles_y = (x->H + C2I_T - 1) / C2I_T;
   const dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(x->N * groups));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -695,6 +695,12 @@ def dcn_columns(x: FM, om: FM, groups: int) -> FM:
     return col
 
 
+# Run-to-run reproducible training (tests/test_model_gpu.py trains its operating-point model with it): the one operator whose
+# result depends on arrival order -- the float atomics of the DCN's bilinear scatter for samples displaced out of their
+# tile's window -- records those samples and adds them in sorted key order instead.  Costs a host synchronisation per step.
+DETERMINISTIC = False
+
+
 def dcn_col2im(x: FM, om: FM, dcol: FM, groups: int, dom: FM) -> FM:
     """-> dx as an fp32 FM (fresh; scatter through per-tile windows); offset / mask gradients accumulate into `dom`"""
     dx32 = FM.zeros(x.N, x.H, x.W, x.C, dtype=torch.float32, device=x.t.device)
@@ -702,6 +708,21 @@ def dcn_col2im(x: FM, om: FM, dcol: FM, groups: int, dom: FM) -> FM:
     nwork = lib.tdvc_dcn_col2im_work_floats(x.N, x.H, x.W, groups)
     work = torch.empty((nwork,), dtype=torch.float32, device=x.t.device)
     d1, d2, d3, d4 = x.desc(), om.desc(), dcol.desc(), dom.desc()
+    if DETERMINISTIC:
+        dev = x.t.device
+        cap = max(1 << 16, x.N * x.H * x.W * groups * 36 // 8)          # an eighth of all samples far out of their window
+        keys = torch.empty((cap,), dtype=torch.int64, device=dev)
+        vals = torch.empty((cap, 8), dtype=torch.float32, device=dev)
+        cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+        L.check(lib.tdvc_dcn_col2im_det(C.byref(d1), C.byref(d2), C.byref(d3), groups, dx32.t.data_ptr(), C.byref(d4), work.data_ptr(), nwork,
+                                        keys.data_ptr(), vals.data_ptr(), cnt.data_ptr(), cap, _stream()), "dcn_col2im_det")
+        n = int(cnt.item())
+        if n > cap:
+            raise L.TdvcHipError(f"dcn_col2im (deterministic): {n} far samples exceed the record capacity {cap}")
+        if n:
+            ks, order = torch.sort(keys[:n], stable=True)
+            L.check(lib.tdvc_dcn_far_apply(ks.data_ptr(), order.data_ptr(), vals.data_ptr(), n, dx32.t.data_ptr(), _stream()), "dcn_far_apply")
+        return dx32
     L.check(lib.tdvc_dcn_col2im(C.byref(d1), C.byref(d2), C.byref(d3), groups, dx32.t.data_ptr(), C.byref(d4), work.data_ptr(), nwork, _stream()),
             "dcn_col2im")
     return dx32

@@ -96,9 +96,12 @@ class GradBuckets:
         for b in self.buckets:
             b.zero_()
 
-    @staticmethod
-    def _distributed() -> bool:
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    # test hook (tests/test_train_dist_gpu.py): take the asynchronous all-reduce path in a process group of ONE rank, so that
+    # RCCL's stream ordering against the side-stream weight-gradient kernels can be exercised on a single GPU
+    force_async = False
+
+    def _distributed(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_async)
 
     def node_done(self, k: int):
         for i in self._by_ready.get(k, ()):

@@ -150,9 +150,8 @@ def test_forward_vs_oracle_1080p(models, report):
     `pad(., 64)`): ONE P-frame on the HIP path and on the fp32 CPU oracle (about a minute of CPU).  This is where the
     geometry differs from every smaller case: FeatureFix scale = int(1088 / 8) = 136 with floor pooling (1920 / 136 = 14.1,
     the last 16 px dropped), 408-px gather blocks overhanging the frame, centred 4 + 4 row padding, > 256 tiles per
-    persistent workgroup in every conv kernel.  Gates: |dPSNR| <= 0.02 dB, patch-match indices bit-equal; dbpp reported
-    and gated at 0.001 + 0.5 % like the small cases (the 0.001-absolute gate is asserted at a trained operating point in
-    test_trained_operating_point_parity)."""
+    persistent workgroup in every conv kernel.  Gates: the north_star's own, absolute: |dPSNR| <= 0.02 dB and |dbpp| <= 0.001
+    on the frame's total rate; patch-match indices bit-equal."""
     import time
     import torch.nn.functional as F
     from tdvc_amd.synth import make_gop, ref_list
@@ -177,7 +176,9 @@ def test_forward_vs_oracle_1080p(models, report):
     report("   stage rel-L2: " + " ".join(f"{k}={v:.2e}" for k, v in st.items()))
     assert idx_o.shape == (1, 24) and torch.equal(idx_g, idx_o), f"patch argmax differs: {idx_g.tolist()} vs {idx_o.tolist()}"
     assert abs(p_o - p_g) <= 0.02, f"PSNR delta {p_o - p_g}"
-    assert abs(float(bro) - float(brg)) <= 1e-3 + 5e-3 * float(bro) and abs(float(bmo) - float(bmg)) <= 1e-3 + 5e-3 * float(bmo)
+    # SURVEY 8d / north_star, absolute, at the size they are stated for: |d bpp| <= 0.001 on the frame's total rate (a 4.66 bpp
+    # frame with the filler weights: 0.02 % of the rate; measured +0.0008)
+    assert abs(float(brg + bmg) - float(bro + bmo)) <= 1e-3, f"bpp delta {float(brg + bmg) - float(bro + bmo):+.5f} misses the absolute 0.001 gate"
     for k in ("f_cur", "f_ref", "estmv"):
         assert st[k] < 1e-2, (k, st[k])
     for k in ("pred1", "pred", "resid"):
@@ -217,8 +218,10 @@ def _train_to_operating_point(report, max_iters=600, target_bpp=0.30, lam=256.0)
     initialisation until the training-mode rate is under `target_bpp`; -> (model in eval mode, log of the last step)"""
     from tdvc_amd.model import VideoCompressor
     from tdvc_amd.synth import fill_parameters, make_gop, ref_list
+    from tdvc_amd import ops
     from tdvc_amd.train import TrainStep
     torch.manual_seed(1111)                                   # tools/train.py:253-256
+    ops.DETERMINISTIC = True                                  # run-to-run reproducible steps: every suite run tests the SAME model
     net = VideoCompressor()
     fill_parameters(net)
     net = net.cuda().train()
@@ -240,27 +243,41 @@ def _train_to_operating_point(report, max_iters=600, target_bpp=0.30, lam=256.0)
             report(f"   train-to-operating-point it {it + 1}: rd_loss {log['rd_loss']:.4f} bpp {bpp:.4f} (ema {ema:.4f}) mse {log['mse']:.2e}")
         if it >= 100 and ema <= target_bpp:
             break
-    report(f"   trained {it + 1} iterations (lambda {lam:g}): training-mode bpp ema {ema:.4f}")
+    ops.DETERMINISTIC = False
+    import hashlib
+    hsh = hashlib.sha256()
+    for k, v in sorted(net.state_dict().items()):
+        hsh.update(k.encode()); hsh.update(v.detach().cpu().contiguous().numpy().tobytes())
+    report(f"   trained {it + 1} iterations (lambda {lam:g}): training-mode bpp ema {ema:.4f}; state-dict sha256 {hsh.hexdigest()[:16]} "
+           f"(deterministic TrainSteps from seed 1111: the same digest on every run of this build)")
     return net.eval(), ema
 
 
-def test_trained_operating_point_parity(report):
-    """SURVEY 8d's absolute gates (|dbpp| <= 0.001, |dPSNR| <= 0.02 dB) at a TRAINED-like operating point instead of the
-    several-bpp filler weights: 600 TrainSteps bring the rate to a few tenths of a bpp, the state-dict moves to the fp32 CPU
-    oracle (strict=True), and P-frames at 256x256 and 512x768 are coded by both, in the default (fp16 coders) mode and in the
-    fp32-island mode.  Both differences are sums of rare discrete events (a quantiser symbol that falls on the other side of
-    .5 because the features upstream are fp16; in the motion latents it also changes the prediction), the trained weights
-    are not bit-reproducible from run to run, and a 65 k-pixel frame does not average such events out: the gates are therefore
-    asserted on the median over the frames (PSNR: 0.03 dB, see the note at the assertion) with three times the SURVEY gate
-    as the bound on every single frame (rate at 512x768: the gate itself per frame), next to the direct statement that the
-    two reconstructions agree to > 65 dB; the 256x256 rate of the default mode over 18 frames as a distribution (below)."""
+@pytest.fixture(scope="module")
+def trained(report):
+    """(HIP model, fp32 CPU oracle with the same state-dict) at the trained operating point; built once per module run"""
     from oracle.tdvc_ref import VideoCompressor as Ref
-    from tdvc_amd.synth import make_gop, ref_list
     net, ema = _train_to_operating_point(report)
     ref = Ref().eval()
     ref.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()}, strict=True)
+    return net, ref
+
+
+def test_trained_operating_point_parity(trained, report):
+    """SURVEY 8d's absolute gates (|dbpp| <= 0.001, |dPSNR| <= 0.02 dB) at a TRAINED-like operating point instead of the
+    several-bpp filler weights: <= 600 deterministic TrainSteps (ops.DETERMINISTIC: the same weights on every run, digest in
+    the report) bring the rate to a few tenths of a bpp, the state-dict moves to the fp32 CPU oracle (strict=True), and
+    P-frames at 256x256 and 512x768 are coded by both, in the default (fp16 coders) mode and in the fp32-island mode.  Both
+    differences are sums of rare discrete events (a quantiser symbol that falls on the other side of .5 because the features
+    upstream are fp16; in the motion latents it also changes the prediction) and a 65 k-pixel frame does not average such
+    events out: from 512x768 up the gates themselves are asserted per frame (the headline size: the next test); at 256x256
+    the PSNR gate holds for the median with three times the gate on every single frame, the rate as a distribution over 18
+    frames (below), next to the direct statement that the two reconstructions agree to > 65 dB."""
+    from tdvc_amd.synth import make_gop, ref_list
+    net, ref = trained
     worst, d256, dps = 0.0, [], []
     for (H, W, seeds) in ((256, 256, (1234, 1235, 1236)), (512, 768, (1234,))):
+        big = H * W >= 512 * 768
         for seed in seeds:
             g = make_gop(seed, 3, H, W)
             refs_l = [g[0:1]]
@@ -281,9 +298,10 @@ def test_trained_operating_point_parity(report):
                 # model): at 33-36 dB a deviation of 8e-5 RMS can move the PSNR by up to 0.04 dB, measured 0.002-0.022 dB
                 agree16, agree32 = psnr(r16.cpu(), ro), psnr(r32.cpu(), ro)
                 assert agree16 >= 65.0 and agree32 >= 65.0, f"reconstructions differ: PSNR(gpu, oracle) {agree16:.1f} / {agree32:.1f} dB"
-                assert abs(p_16 - p_o) <= 0.06 and abs(p_32 - p_o) <= 0.06, "a frame misses three times the SURVEY 8d PSNR gate"
-                assert abs(d32) <= (1e-3 if H * W >= 512 * 768 else 3e-3), "fp32-island mode misses the rate bound at the trained operating point"
-                if H * W >= 512 * 768:
+                gate_p = 0.02 if big else 0.06
+                assert abs(p_16 - p_o) <= gate_p and abs(p_32 - p_o) <= gate_p, f"a {H}x{W} frame misses the {gate_p} dB PSNR bound"
+                assert abs(d32) <= (1e-3 if big else 3e-3), "fp32-island mode misses the rate bound at the trained operating point"
+                if big:
                     assert abs(d16) <= 1e-3, "default mode misses the SURVEY 8d rate gate at the trained operating point"
                 else:
                     d256.append(d16)
@@ -293,7 +311,7 @@ def test_trained_operating_point_parity(report):
     med = lambda vals: sorted(vals)[len(vals) // 2]
     report(f"[trained, {len(dps)} oracle frames] median |dPSNR| default {med([v[0] for v in dps]):.4f} islands {med([v[1] for v in dps]):.4f} dB; "
            f"median |dbpp| islands {med([v[2] for v in dps]):.5f}")
-    assert med([v[0] for v in dps]) <= 0.03 and med([v[1] for v in dps]) <= 0.03 and med([v[2] for v in dps]) <= 1e-3
+    assert med([v[0] for v in dps]) <= 0.02 and med([v[1] for v in dps]) <= 0.02 and med([v[2] for v in dps]) <= 1e-3
     # The default mode's rate at 256x256 over 6 + 12 frames; the fp32-island mode (= the oracle's bits on identical coder
     # inputs, asserted above) is the reference of the extra 12.  tools/trained_point_sweep.py: median 2-3e-5 bpp, 1-2 of 32
     # frames over 1e-3 (up to 2.4e-3); none of 32 at 512x768; at 1088x1920 the same events are 30x smaller per pixel.
@@ -310,3 +328,34 @@ def test_trained_operating_point_parity(report):
     a256 = sorted(abs(v) for v in d256)
     report(f"[trained, 256x256, {len(a256)} frames] default mode |dbpp|: median {a256[len(a256) // 2]:.5f} max {a256[-1]:.5f}, over 0.001: {sum(v > 1e-3 for v in a256)}")
     assert a256[len(a256) // 2] <= 5e-4 and sum(v > 1e-3 for v in a256) <= 5 and a256[-1] <= 5e-3
+
+
+def test_trained_operating_point_parity_1080p(trained, report):
+    """The north_star gates at the size AND in the regime they are stated for: one P-frame of the cfg-2 GOP at 1088x1920 coded
+    with the trained weights by the HIP path (default mode and fp32 islands) and by the fp32 CPU oracle (about a minute):
+    |dPSNR| <= 0.02 dB (on the 1080 visible rows, predict.py:69-70,87) and |dbpp| <= 0.001, absolute, per frame, both modes;
+    patch-match indices bit-equal."""
+    import time
+    import torch.nn.functional as F
+    from tdvc_amd.synth import make_gop, ref_list
+    net, ref = trained
+    g = F.pad(make_gop(1234, 2, 1080, 1920), (0, 0, 4, 4))
+    refs = ref_list([g[0:1]])
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    tr16 = {}
+    with torch.no_grad():
+        t0 = time.time()
+        ro, bro, bmo = ref(g[1:2], refs, False)
+        t_cpu = time.time() - t0
+        r16, br16, bm16 = net(g[1:2].cuda(), refs.cuda(), True, trace=tr16)
+        r32, br32, bm32 = net(g[1:2].cuda(), refs.cuda(), False)
+    crop = lambda t: t[:, :, 4:-4]
+    bo = float(bro + bmo)
+    p_o, p_16, p_32 = psnr(crop(ro), crop(g[1:2])), psnr(crop(r16.cpu()), crop(g[1:2])), psnr(crop(r32.cpu()), crop(g[1:2]))
+    d16, d32 = float(br16 + bm16) - bo, float(br32 + bm32) - bo
+    report(f"[trained, 1088x1920] oracle {t_cpu:.1f} s | oracle {bo:.5f} bpp {p_o:.4f} dB | default mode dbpp {d16:+.6f} dPSNR {p_16 - p_o:+.5f} | "
+           f"fp32 islands dbpp {d32:+.6f} dPSNR {p_32 - p_o:+.5f} | PSNR(gpu, oracle) {psnr(r16.cpu(), ro):.1f} / {psnr(r32.cpu(), ro):.1f} dB")
+    assert bo < 1.0, "not a trained-like operating point"
+    assert torch.equal(tr16["ff_idx"].cpu().long(), ref.loopfilter.last_match_index), "in-loop filter patch argmax differs"
+    assert abs(p_16 - p_o) <= 0.02 and abs(p_32 - p_o) <= 0.02, "PSNR gate (0.02 dB) missed at 1088x1920"
+    assert abs(d16) <= 1e-3 and abs(d32) <= 1e-3, "rate gate (0.001 bpp) missed at 1088x1920"

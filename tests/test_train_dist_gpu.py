@@ -69,3 +69,63 @@ def test_two_rank_train_step_overlapped_all_reduce(report):
     assert res["same"] and res["finite"]
     assert res["grad_norms"][0] == res["grad_norms"][1]           # the clipping norm is taken after the mean
     assert res["in_sweep"] >= 1
+
+
+def _nccl_worker(port, q):
+    """ONE rank, backend nccl (= RCCL): the bucket all-reduces are started from the tape hook while weight-gradient kernels
+    run on the side stream.  gloo copies after a host synchronisation; RCCL is ordered against the CURRENT stream at call
+    time only, so a missing side-stream -> current-stream dependency would let a reduction read (and, in place, overwrite)
+    a bucket whose last weight gradient is still being accumulated.  With one rank the reduction is the identity: the
+    parameters after three steps must equal the non-distributed run bit for bit."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    from tdvc_amd import ops, synth
+    from tdvc_amd.model.pnet import VideoCompressor
+    from tdvc_amd.train import TrainStep
+    ops.DETERMINISTIC = True                          # the DCN scatter's float atomics are the one order-dependent operator
+    gop = synth.make_gop(500, 7, 128, 128).float()
+    x = torch.cat([gop[3:4], gop[4:5]]).cuda()
+    refs = torch.stack([torch.stack([gop[0], gop[0], gop[1], gop[2]]), torch.stack([gop[0], gop[1], gop[2], gop[3]])]).cuda()
+
+    def run(force):
+        torch.manual_seed(11)
+        m = VideoCompressor()
+        synth.fill_parameters(m)
+        m = m.cuda()
+        step = TrainStep(m, train_lambda=2048.0, lr=1e-4, loss_scale=128.0)
+        step.buckets.force_async = force
+        started = []
+        orig = step.buckets.node_done
+
+        def spy(k):
+            orig(k)
+            started.append(len(step.buckets._works))
+        step.buckets.node_done = spy
+        logs = [step(x, refs) for _ in range(3)]
+        torch.cuda.synchronize()
+        return torch.cat([p.detach().reshape(-1).float().cpu() for p in step.main_params]), logs, (max(started) if started else 0), len(step.buckets.buckets)
+
+    p_plain, l_plain, _, _ = run(False)
+    p_nccl, l_nccl, in_sweep, nb = run(True)
+    p_again, _, _, _ = run(False)
+    q.put(dict(equal=bool(torch.equal(p_plain, p_nccl)), repro=bool(torch.equal(p_plain, p_again)), in_sweep=in_sweep, nbuckets=nb,
+               maxdiff=float((p_plain - p_nccl).abs().max()), loss=[l["rd_loss"] for l in l_plain], loss_nccl=[l["rd_loss"] for l in l_nccl]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_async_all_reduce_stream_order(report):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=900)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    report(f"1-rank RCCL train steps: parameters bit-equal to the non-distributed run: {res['equal']} (max |diff| {res['maxdiff']:.3g}); "
+           f"non-distributed run reproducible: {res['repro']}; {res['in_sweep']} of {res['nbuckets']} bucket all-reduces started inside "
+           f"the backward sweep; rd_loss {res['loss']} vs {res['loss_nccl']}")
+    assert res["repro"], "the deterministic training step is not reproducible run to run"
+    assert res["in_sweep"] >= 1, "no all-reduce was started from the tape hook"
+    assert res["equal"], "asynchronous RCCL all-reduces changed the result: a stream dependency is missing"

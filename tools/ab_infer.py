@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """A/B inside ONE process: median 1080p P-frame time with two statements toggled (names in scope: net, lib, torch).
 python tools/ab_infer.py "stmt_a" "stmt_b" """
 import ctypes

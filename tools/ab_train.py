@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """A/B inside ONE process (box-to-box and run-to-run noise is larger than the effects measured here): median step time
 of TrainStep with an attribute toggled.  python tools/ab_train.py attr value_a value_b
 or with two statements (names in scope: step, lib, torch):  python tools/ab_train.py exec "stmt_a" "stmt_b" """

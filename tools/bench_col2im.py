@@ -1,7 +1,8 @@
 """dcn_col2im timing vs the spread of the offsets (the scatter window is +-8 pixels around a 16x16 tile)."""
+import os
 import sys
 import torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tdvc_amd import ops
 from tdvc_amd.ops import FM
 

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Kernel-level timing of representative hot-path layers at 1080p (HIP events on the launch stream).
 Usage: python tools/bench_conv.py [--iters 20]"""
 import argparse

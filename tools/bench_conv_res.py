@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """3x3 64->64 @1088x1920 with 0 / 1 / 2 fp16 residuals (fresh output buffers in rotation, so the writes are not
 absorbed by the Infinity Cache): conv_mfma_v10 vs conv_mfma_v7 (in-process A/B through the debug switch)."""
 import ctypes

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """fused DCN forward at 1088x1920 (8 groups, offsets ~N(0, sigma px)): NHWC gather vs the group-planar gather (incl. its
 re-layout pass), HIP events on the launch stream.  Usage: python tools/bench_dcn.py [sigma ...]"""
 import os

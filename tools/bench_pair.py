@@ -1,7 +1,8 @@
 """tdvc_conv_pair against the same pair as two tdvc_conv2d launches: python tools/bench_pair.py [H W N reps]"""
+import os
 import sys
 import torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tdvc_amd import ops
 
 H, W, N, reps = (int(v) for v in (sys.argv[1:5] + ["1088", "1920", "1", "20"][len(sys.argv) - 1:]))

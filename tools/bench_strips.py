@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Does running a conv chain strip-by-strip keep intermediates in the 256 MB Infinity Cache?
 chain of K 3x3 64->64 convs at 1088x1920: whole-frame layer by layer vs S horizontal strips."""
 import os

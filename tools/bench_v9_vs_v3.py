@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """small-map layers on conv_mfma_v9 (split-K, operands from L2) vs the tiled kernels: where is the crossover?"""
 import ctypes
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """offset statistics of the fused DCN call inside a 1080p P-frame of the bench (filler weights, synthetic GOP)"""
 import os
 import sys

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """diagnostic: per-launch table of the conv kernels of one 1080p P-frame (HIP events on the launch stream)"""
 import os
 import sys

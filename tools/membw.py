@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """diagnostic: achievable HBM rates of plain torch kernels at feature-map sizes (fill / copy / add), cycling over
 several buffers so that the 256 MB Infinity Cache does not absorb the traffic"""
 import torch

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """run ONE layer repeatedly (for rocprofv3 --pmc): python tools/one_conv.py cin cout k stride H W iters"""
 import os
 import sys

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """run the fused DCN forward repeatedly on a 1080p map with bench-like offsets (|.| ~ 1, groups uncorrelated): for
 rocprofv3 --pmc.  python tools/one_dcn.py iters [sigma]"""
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """run ONE fused conv pair repeatedly (for rocprofv3 --pmc): python tools/one_pair.py H W iters"""
 import os
 import sys

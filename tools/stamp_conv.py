@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """diagnostic: per-phase cycle stamps of conv_mfma_v2 (wave 0 of each workgroup)"""
 import ctypes
 import os

@@ -1,7 +1,8 @@
 """per-step cycle breakdown of conv_pair (steady-state steps): python tools/stamp_pair.py [H W]"""
+import os
 import ctypes, sys
 import torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tdvc_amd import ops
 
 H, W = (int(v) for v in (sys.argv[1:3] + ["1088", "1920"][len(sys.argv) - 1:]))

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """diagnostic: per-wave phase stamps of conv_mfma_v10 (the instrumented stage = second stage of the second tile of every
 workgroup): top-of-stage wait, barrier, the six matrix groups, tile barrier, epilogue pieces.  Usage: stamp_v10.py H W [nres]"""
 import ctypes

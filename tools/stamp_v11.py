@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """diagnostic: per-wave phase stamps of conv_mfma_v11 (last stage of every workgroup's second tile + the stage before it).
 Usage: stamp_v11.py cin cout H W [nres]"""
 import ctypes

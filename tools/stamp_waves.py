@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """diagnostic: per-wave phase stamps of conv_mfma_v7 (stage 3 of every workgroup), relative to the
 workgroup's earliest stamp.  Usage: stamp_waves.py cin cout H W"""
 import ctypes

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """diagnostic: cycles per phase of conv_wgrad_kernel, per wave, summed over a workgroup's pixel blocks.
 Usage: stamp_wgrad.py cin cout k N H W"""
 import ctypes

@@ -1,8 +1,9 @@
 """repeat the conv_pair cases most exposed to synchronisation holes (short segments, ragged strips, second residual) and
 compare every launch with the first: python tools/stress_pair.py [reps]"""
+import os
 import sys
 import torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tdvc_amd import ops
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300

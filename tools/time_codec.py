@@ -1,5 +1,6 @@
+import os
 import sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tdvc_amd.model import VideoCompressor
 from tdvc_amd.synth import fill_parameters, make_gop, ref_list
 from tdvc_amd.codec_utils import pad

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """diagnostic: per-launch table of the conv kernels (forward, data-gradient and weight-gradient launches) of one training
 step at 4 x 256x256 (HIP events on the launch stream)"""
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Where does the PSNR / rate difference against the fp32 CPU oracle come from at a trained-like operating point?
 Trains like tests/test_model_gpu.py::_train_to_operating_point, then per frame: FeatureFix patch indices equal?, stage-wise
 relative L2 of the trace against the oracle's, symbol flips.  python tools/trained_point_diag.py [iters]"""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Rate of the default (fp16) coders against the fp32-island coders (= the fp32 CPU oracle's bits on identical coder inputs)
 at a TRAINED-like operating point, over many frames: python tools/trained_point_sweep.py [n_gops] [iters]
 Prints |dbpp| statistics at 256x256 and 512x768.  (Round 2: median 2-3e-5 bpp at both sizes; 1-2 of 32 frames at 256x256 reach
