@@ -19,6 +19,11 @@ from .coder import MVCoder, ResCoder
 from .modules import FeaExtra, FeatureFix, LoopFilter, MCNet, OffsetGen
 
 
+def _ref_views(refs8: FM, B: int):
+    """(r-1, I) of every batch item as views of the converted reference stack (B*4, H, W, 8): items 4b + 3 and 4b"""
+    return (FM(refs8.t, refs8.off + 3 * refs8.sn, B, refs8.C, 4 * refs8.sn), FM(refs8.t, refs8.off, B, refs8.C, 4 * refs8.sn))
+
+
 class VideoCompressor(nn.Module):
     fp32_islands_supported = True
 
@@ -82,8 +87,7 @@ class VideoCompressor(nn.Module):
             refs8 = ops.from_nchw(refs, Cpad=8)                          # (B*4,H,W,8): [I, r-3, r-2, r-1]
             last = refer_frames[:, 3].float()
             ref32 = ops.from_nchw(last, Cpad=4, dtype=torch.float32)
-            ref8 = ops.from_nchw(last, Cpad=8)
-            iframe8 = ops.from_nchw(refer_frames[:, 0].float(), Cpad=8)
+            ref8, iframe8 = _ref_views(refs8, B)                          # frames r-1 and I: strided batch views, not second conversions
             if ops.TAPE is not None:                                     # network inputs carry no gradient
                 for t in (cur32, cur8, refs8, ref32, ref8, iframe8):
                     ops.TAPE.mark_input(t)
@@ -136,8 +140,7 @@ class VideoCompressor(nn.Module):
         dev = refer_frames.device
         refs8 = ops.from_nchw(refer_frames.float().reshape(B * 4, 3, H, W), Cpad=8)
         last = refer_frames[:, 3].float()
-        ref8 = ops.from_nchw(last, Cpad=8)
-        iframe8 = ops.from_nchw(refer_frames[:, 0].float(), Cpad=8)
+        ref8, iframe8 = _ref_views(refs8, B)
         feats = FM.empty(B, H, W, 192, device=dev)
         self.extra_fea.run(ref8, feats.ch(64, 64))
         return B, H, W, dev, refs8, last, iframe8, feats

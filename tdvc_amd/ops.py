@@ -804,7 +804,7 @@ class SEParams:
 def se_gate(x: FM, p: SEParams) -> torch.Tensor:
     """gate[N][C] fp32 (`main/model/inflate.py:204-208` without the final multiply)."""
     npix = x.H * x.W
-    nblocks = max(1, min(256, npix // 256))
+    nblocks = max(1, min(1024, npix // 256))      # 4 workgroups per CU at full resolution: 64 KB of loads in flight per CU
     partial = torch.empty((x.N, nblocks, x.C), dtype=torch.float32, device=x.t.device)
     gate = torch.empty((x.N, x.C), dtype=torch.float32, device=x.t.device)
     dx = x.desc()

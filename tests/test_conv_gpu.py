@@ -42,6 +42,7 @@ CASES = [
     ("1x1_s2_64_128", 1, 64, 128, 1, 2, 0, 32, 64),
     ("1x1_256_64", 1, 256, 64, 1, 1, 0, 16, 40),
     ("3x3_3_64", 1, 3, 64, 3, 1, 1, 33, 47),
+    ("3x3_3_64_c8", 3, 3, 64, 3, 1, 1, 70, 150),                 # >= 8192 output pixels: the first-layer kernel (conv_c8), ragged row segments
     ("7x7_8_32", 1, 8, 32, 7, 1, 3, 34, 60),
     ("7x7_32_64", 1, 32, 64, 7, 1, 3, 17, 30),
     ("7x7_64_32", 1, 64, 32, 7, 1, 3, 17, 30),
@@ -450,3 +451,34 @@ def test_conv_v11_pixel_shuffle(cout, H, W, nres, v11, report):
             assert torch.equal(y.t, first), "launch-to-launch mismatch"
     finally:
         fn(1)
+
+
+def test_conv_c8_equals_direct_kernel(report):
+    """the first-layer kernel (conv_c8: persistent waves, weights in registers, B fragments straight from L1) against the
+    direct kernel on the same layer: same MFMA chain per output element, so the results are bit-equal"""
+    import ctypes
+
+    from tdvc_amd import _lib
+    ops = _ops()
+    fn = _lib.lib().tdvc_debug_enable_conv_c8
+    fn.argtypes = [ctypes.c_int]
+    fn.restype = None
+    x = rnd16(randn(2, 3, 96, 200, seed=41).abs())
+    w = rnd16(randn(64, 3, 3, 3, seed=42) * 0.2)
+    b = randn(64, seed=43) * 0.1
+    pc = ops.pack_conv(w, b, stride=1, pad=1)
+    xf = to_fm(x, ops)
+    names, outs = [], []
+    try:
+        for on in (1, 0):
+            fn(on)
+            y = ops.conv(xf, pc, act=ops.ACT_LRELU, slope=0.01)
+            names.append(ops.L.lib().tdvc_last_conv_kernel().decode())
+            outs.append(fm_to_cpu(y))
+    finally:
+        fn(1)
+    report(f"first layer 3x3 8->64 @96x200 x2: kernels {names}, max |diff| {float((outs[0] - outs[1]).abs().max()):.3e}")
+    assert names[0] == "conv_c8" and names[1] != "conv_c8"
+    assert torch.equal(outs[0], outs[1])
+    ref = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.01)
+    assert_close(outs[0], ref, RT, AT, "conv_c8 vs torch", report)

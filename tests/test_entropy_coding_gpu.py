@@ -256,17 +256,61 @@ def test_fp32_island_bitstreams_equal_oracle(coders, H, W, report):
     assert zs[0] == enc_o["strings"][1][0], "z byte string differs from the oracle's compress()"
     if nflip and H * W >= 1088 * 1920:
         # A million symbols: two correctly rounded fp32 contractions (the MFMA's k-ordered fma chain here, the CPU library's
-        # blocked sums in the oracle) differ in the last bits, and a latent within ~1e-6 of a rounding boundary can fall on
-        # either side.  Such a TIE is reported, not hidden: the first differing symbol in coding order (every later one may be
-        # its consequence through the context model) must sit on the boundary, and the count must stay at that level.
+        # blocked sums in the oracle) differ in the last bits, and a latent within ~1e-6 of a rounding boundary falls on either
+        # side (measured: the first such TIE after 126 629 symbols, 4e-7 from the boundary).  One flipped symbol changes y_hat
+        # by 1, and through the context model of an untrained network everything coded after it: a free-running byte
+        # comparison can only hold up to the first tie.  Asserted instead: (a) everything BEFORE the first differing symbol
+        # is bit-equal and that symbol sits on the rounding boundary; (b) teacher-forced (below): with the ORACLE's y_hat as
+        # context, all 8 160 positions at once, every symbol / CDF index that differs from the oracle's is itself a tie.
         with torch.no_grad():
             y_o = ref.g_a(x)[0].permute(1, 2, 0).reshape(-1)                 # (h, w, c) order of the symbol list
-        mean_o = enc_o["_debug"][0]["y_hat"][0].permute(1, 2, 0).reshape(-1) - sym_o.float()
+        yh_o = enc_o["_debug"][0]["y_hat"]                                   # (1, M, h, w)
+        mean_o = yh_o[0].permute(1, 2, 0).reshape(-1) - sym_o.float()
         first = int((sym != sym_o).nonzero()[0])
         dist = abs(abs(float(y_o[first] - mean_o[first]) - float(sym_o[first])) - 0.5)
+        idx_g = d["indexes"].cpu().view(-1)
+        first_idx = int((idx_g != idx_o).nonzero()[0]) if nidx else sym.numel()
         report(f"fp32 islands {H}x{W}: first differing symbol at flat index {first} (position {first // 128}, channel {first % 128}): "
-               f"|y - mean - q| is {dist:.2e} from the rounding boundary; {nflip} of {sym.numel()} symbols differ in all")
-        assert dist <= 2e-5 and nflip <= 1e-4 * sym.numel(), "symbols differ beyond rounding ties at the fp32 boundary"
+               f"|y - mean - q| is {dist:.2e} from the rounding boundary; first differing CDF index at {first_idx}; {nflip} of {sym.numel()} "
+               f"symbols differ after it (cascade through the context model)")
+        assert dist <= 2e-5, "the first differing symbol is not a rounding tie"
+        assert bool((sym[:first] == sym_o[:first]).all())                   # by construction of `first`: the prefix is bit-equal
+        # (b) teacher-forced: gather the causal neighbourhoods of ALL positions from the oracle's y_hat, run the context conv +
+        # entropy_parameters chain once over the 8 160 positions, quantise the GPU's own y against the resulting means
+        M, Hl, Wl = 128, H // 16, W // 16
+        npos = Hl * Wl
+        xf32 = m._as_f32(xf)
+        y32, y16 = m.run_g_a(xf32)
+        z = m.run_h_a(y16)
+        med = m.entropy_bottleneck.quantiles.detach()[:, 0, 1].float().contiguous()
+        z_hat = ops.FM((ops.round_symbols(z, med).float() + med))
+        params = ops.FM.empty(1, Hl, Wl, 2 * M, dtype=torch.float32, device="cuda")
+        m.run_h_s(z_hat, out=params)
+        yh_fm = ops.FM(yh_o.permute(0, 2, 3, 1).contiguous().cuda())
+        pos = torch.tensor([[h, w] for h in range(Hl) for w in range(Wl)], dtype=torch.int32, device="cuda")
+        chain = m._ar_chain(npos, torch.float32, "cuda")
+        ops.ar_gather(yh_fm, params, pos, npos, chain["x1"], chain["pc"])
+        import ctypes as C
+        for dsc in chain["descs"]:
+            ops.L.check(ops.L.lib().tdvc_conv2d(C.byref(dsc), ops._stream()), "conv2d")
+        table = m._coder_tables()[2]
+        sym_t = torch.zeros((Hl, Wl, M), dtype=torch.int32, device="cuda")
+        idx_t = torch.zeros((Hl, Wl, M), dtype=torch.int32, device="cuda")
+        yh_t = ops.FM.zeros(1, Hl, Wl, M, dtype=torch.float32, device="cuda")
+        ops.ar_quantize(y32, chain["gp"], pos, npos, table, yh_t, sym_t, idx_t)
+        sym_t, idx_t = sym_t.cpu().view(-1), idx_t.cpu().view(-1)
+        gp = chain["gp"].t.view(-1, 2 * M)[:npos].cpu()
+        bad = (sym_t != sym_o).nonzero().view(-1)
+        dists = ((y_o[bad] - mean_o[bad] - sym_o[bad].float()).abs() - 0.5).abs()
+        badi = (idx_t != idx_o).nonzero().view(-1)
+        tab = table.cpu()
+        sc = gp[:, :M].reshape(-1)[badi].clamp(min=0.11)
+        rel = ((sc[:, None] - tab[None, :]).abs() / tab[None, :]).min(1).values if badi.numel() else torch.zeros(0)
+        report(f"fp32 islands {H}x{W}, teacher-forced over all {npos} positions: {bad.numel()} of {sym_o.numel()} symbols differ "
+               f"(max distance from the rounding boundary {float(dists.max()) if bad.numel() else 0.0:.2e}), {badi.numel()} CDF indexes differ "
+               f"(max relative distance of the scale from a table boundary {float(rel.max()) if badi.numel() else 0.0:.2e})")
+        assert bad.numel() <= 64 and (bad.numel() == 0 or float(dists.max()) <= 2e-5), "teacher-forced symbols differ beyond rounding ties"
+        assert badi.numel() <= 64 and (badi.numel() == 0 or float(rel.max()) <= 2e-5), "teacher-forced CDF indexes differ beyond ties of the scale table"
     else:
         assert ys[0] == enc_o["strings"][0][0], "y byte string differs from the oracle's compress()"
     tr = {}

@@ -253,14 +253,63 @@ def _train_to_operating_point(report, max_iters=600, target_bpp=0.30, lam=256.0)
     return net.eval(), ema
 
 
+def _fp16_exact(sd):
+    """the state-dict with every conv / DCN weight rounded to an fp16-representable value (biases, SE MLPs' use, entropy
+    parameters, GDN parameters untouched): a checkpoint whose weights the HIP path's fp16 packing reproduces EXACTLY"""
+    out = {}
+    for k, v in sd.items():
+        conv_w = k.endswith(".weight") and v.dim() >= 4
+        out[k] = v.detach().half().float() if conv_w else v.detach().clone()
+    return out
+
+
 @pytest.fixture(scope="module")
 def trained(report):
-    """(HIP model, fp32 CPU oracle with the same state-dict) at the trained operating point; built once per module run"""
+    """(HIP model, fp32 CPU oracle, HIP model with the raw master weights) at the trained operating point, built once per module run.
+
+    The checkpoint both paths load is FP16-EXACT in its conv weights (`_fp16_exact`).  Reason (measured, r03): TrainStep
+    optimises the loss of the network the HIP path evaluates, i.e. of the fp16-ROUNDED weights; the fp32 master weights
+    differ from them by the rounding residual, one fixed perturbation of the whole network, and the fp32 oracle loaded
+    with the master weights coded every frame 0.020-0.035 dB WORSE than the HIP path (same sign on all 8 frames and in both
+    coder modes, 1088x1920: +0.0315 dB; |dbpp| 1.5e-4) -- a statement about checkpoint precision, not about kernel
+    arithmetic.  With an fp16-exact checkpoint the two paths evaluate the same function and the north_star gates test what
+    they are meant to test; the master-weight effect is reported by test_trained_master_weights_effect."""
     from oracle.tdvc_ref import VideoCompressor as Ref
-    net, ema = _train_to_operating_point(report)
+    from tdvc_amd.model import VideoCompressor
+    raw, ema = _train_to_operating_point(report)
+    sd = _fp16_exact({k: v.detach().cpu() for k, v in raw.state_dict().items()})
+    net = VideoCompressor()
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
     ref = Ref().eval()
-    ref.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()}, strict=True)
-    return net, ref
+    ref.load_state_dict(sd, strict=True)
+    return net, ref, raw
+
+
+def test_trained_master_weights_effect(trained, report):
+    """what the precision of the CHECKPOINT alone does at the trained operating point: the fp32 CPU oracle with the raw fp32
+    master weights of the training run against the same oracle with the fp16-exact checkpoint (two checkpoints 2^-11 apart,
+    one arithmetic), next to the HIP path (which packs both to the same fp16 conv weights).  Reported, and bounded at three
+    times the north_star gate: this is the deviation a per-frame 0.02 dB gate against master weights would measure before
+    any kernel arithmetic enters."""
+    from oracle.tdvc_ref import VideoCompressor as Ref
+    from tdvc_amd.synth import make_gop, ref_list
+    net, ref, raw = trained
+    ref_raw = Ref().eval()
+    ref_raw.load_state_dict({k: v.detach().cpu() for k, v in raw.state_dict().items()}, strict=True)
+    g = make_gop(1234, 3, 256, 256)
+    refs_l = [g[0:1]]
+    for t in (1, 2):
+        refs = ref_list(refs_l)
+        with torch.no_grad():
+            r_e, br_e, bm_e = ref(g[t:t + 1], refs, False)
+            r_m, br_m, bm_m = ref_raw(g[t:t + 1], refs, False)
+            r_g, br_g, bm_g = net(g[t:t + 1].cuda(), refs.cuda(), True)
+        pe, pm, pg = psnr(r_e, g[t:t + 1]), psnr(r_m, g[t:t + 1]), psnr(r_g.cpu(), g[t:t + 1])
+        report(f"[trained, 256x256 frame {t}] oracle, fp16-exact checkpoint {pe:.4f} dB {float(br_e + bm_e):.5f} bpp | oracle, fp32 master weights "
+               f"{pm:.4f} dB ({pm - pe:+.4f}) {float(br_m + bm_m):.5f} bpp ({float(br_m + bm_m) - float(br_e + bm_e):+.5f}) | HIP path {pg:.4f} dB ({pg - pe:+.4f})")
+        assert abs(pm - pe) <= 0.06 and abs(float(br_m + bm_m) - float(br_e + bm_e)) <= 3e-3
+        refs_l.append(r_e)
 
 
 def test_trained_operating_point_parity(trained, report):
@@ -274,7 +323,7 @@ def test_trained_operating_point_parity(trained, report):
     the PSNR gate holds for the median with three times the gate on every single frame, the rate as a distribution over 18
     frames (below), next to the direct statement that the two reconstructions agree to > 65 dB."""
     from tdvc_amd.synth import make_gop, ref_list
-    net, ref = trained
+    net, ref, _ = trained
     worst, d256, dps = 0.0, [], []
     for (H, W, seeds) in ((256, 256, (1234, 1235, 1236)), (512, 768, (1234,))):
         big = H * W >= 512 * 768
@@ -338,7 +387,7 @@ def test_trained_operating_point_parity_1080p(trained, report):
     import time
     import torch.nn.functional as F
     from tdvc_amd.synth import make_gop, ref_list
-    net, ref = trained
+    net, ref, _ = trained
     g = F.pad(make_gop(1234, 2, 1080, 1920), (0, 0, 4, 4))
     refs = ref_list([g[0:1]])
     torch.set_num_threads(min(16, torch.get_num_threads()))
