@@ -145,6 +145,44 @@ def pmc_traffic_bytes(pmc_file=PMC_FILE):
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
 
 
+def measure_pair_traffic():
+    """HBM bytes per launch of the dominant kernel's representative launch (conv_pair, Res_Block @1088x1920), MEASURED in this
+    run: two `rocprofv3 --pmc` child processes (FETCH_SIZE and WRITE_SIZE need passes of their own: MI355X_MICROARCH.md,
+    rocprofv3 PMC slots) on tools/one_pair.py, started BEFORE this process touches the GPU (a GPU-initialised process
+    starts no child).  gfx950 correction of the guide: a wide coalesced read reports half its bytes -> 2 x FETCH_SIZE.
+    -> (bytes per launch, description) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    vals = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="tdvc_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "r", "--", sys.executable,
+                                os.path.join(ROOT, "tools", "one_pair.py"), str(HP), str(WP), "6"], cwd="/tmp", env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode})"
+            v = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                 if "conv_pair" in row["Kernel_Name"] and row["Counter_Name"] == ctr]
+            if not v:
+                return None, f"no conv_pair rows in the {ctr} pass"
+            vals[ctr] = sum(v) / len(v)
+        except Exception as ex:                                  # never lose the headline line to the profiler
+            return None, f"{type(ex).__name__}: {ex}"[:200]
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, (
+        f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes on tools/one_pair.py {HP} {WP} before the timed region "
+        f"(FETCH_SIZE {vals['FETCH_SIZE']:.0f} KB x 2 [gfx950 wide-read correction] + WRITE_SIZE {vals['WRITE_SIZE']:.0f} KB)")
+
+
 def _time_launches(fn, reps=20):
     """average duration of `reps` back-to-back launches of fn() on torch's current stream (= the launch stream)"""
     fn()
@@ -194,6 +232,9 @@ def hbm_rooflines(model):
     return out
 
 
+LIVE_TRAFFIC = {}      # kernel name -> (bytes per launch, description), filled before the GPU is touched (main)
+
+
 def roofline_leg(runner):
     """(1) one extra P-frame with HIP events around every conv launch (torch's current stream IS the launch
     stream) -> per-instantiation table; (2) the dominant kernel's representative launch (REP_LAUNCHES) timed live over
@@ -237,10 +278,13 @@ def roofline_leg(runner):
         ms = sorted(_time_launches(fn) for _ in range(3))[1]        # median of three loops of 20 back-to-back launches
         ach = flop / (ms * 1e-3) / 1e12
         traffic = pmc_traffic_bytes(L["pmc"])
+        tsrc = (L["pmc"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; not measured in this run)") if traffic else None
+        if kname in LIVE_TRAFFIC and LIVE_TRAFFIC[kname][0]:
+            traffic, tsrc = LIVE_TRAFFIC[kname]
         return {"kernel": kname, "launch": f"{L['what']} on {ran} ({flop / 1e9:.1f} GFLOP, {alg / 1e6:.1f} MB algorithmic)",
                 "achieved": round(ach, 2), "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / MFMA_F16_PEAK, 4),
                 "avg_launch_ms": round(ms, 4), "traffic": traffic,
-                "traffic_source": (L["pmc"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; not measured in this run)") if traffic else None,
+                "traffic_source": tsrc,
                 "hbm_side": {"algorithmic_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "peak_GBps": 8000.0, "frac": round(alg / (ms * 1e-3) / 8e12, 4)},
                 "frame_kernel": {"launches_per_frame": agg[kname]["n"], "ms_per_frame": round(agg[kname]["ms"], 3),
                                  "tflops": round(agg[kname]["flops"] / (agg[kname]["ms"] * 1e-3) / 1e12, 2)} if kname in agg else None}
@@ -319,6 +363,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="1088x1920", help="HxW of the CPU-oracle frame (default: the real 1088x1920 frame, about a minute)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32-island, HBM-roofline and training legs of the N=1 line")
     ap.add_argument("--mode", choices=("infer", "train"), default="infer",
                     help="infer (default, the headline metric) | train: BASELINE.json configs[2]/[3], one optimisation step per step")
@@ -334,6 +379,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if world == 1 and a.mode == "infer" and not a.no_extras and not a.no_pmc:
+        t_, src_ = measure_pair_traffic()                  # child processes: must run before this process initialises the GPU
+        LIVE_TRAFFIC["conv_pair"] = (t_, src_)
+        print(f"[bench] conv_pair traffic: {t_} ({src_})", file=sys.stderr, flush=True)
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -398,6 +398,9 @@ int tdvc_add_flow_backward(const tdvc_fmap* doff, const tdvc_fmap* dflow, void* 
 int tdvc_bcast_add_act_backward(const tdvc_fmap* dx, const tdvc_fmap* x, const tdvc_fmap* db, float slope, void* stream);
 /* adjoint of tdvc_upsample2x: dx += U^T dy. */
 int tdvc_upsample2x_backward(const tdvc_fmap* dy, const tdvc_fmap* dx, void* stream);
+/* adjoint of tdvc_resize_bilinear (flownet.py:153-173, the flow's way back from the x32-padded size): dx += R^T (chscale * dy),
+ * fp32 maps, gathered per input pixel (reproducible).  Only reached when H or W is not a multiple of 32. */
+int tdvc_resize_bilinear_backward(const tdvc_fmap* dy, const tdvc_fmap* dx, const float* chscale, void* stream);
 
 /* backward of tdvc_spynet_level_input (flownet.py:82-140): dflow_up += flow channels of dcat8 + the warp gradient
  * (grid_sample bilinear / border / align_corners=True w.r.t. the flow), then dflow_lo += 2 * U^T dflow_up.  The images

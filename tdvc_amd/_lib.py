@@ -75,6 +75,7 @@ SIGNATURES = {
     "tdvc_add_flow_backward": (_i, [_FM, _FM, _P]),
     "tdvc_bcast_add_act_backward": (_i, [_FM, _FM, _FM, _f, _P]),
     "tdvc_upsample2x_backward": (_i, [_FM, _FM, _P]),
+    "tdvc_resize_bilinear_backward": (_i, [_FM, _FM, _P, _P]),
     "tdvc_spynet_level_input_backward": (_i, [_FM, _FM, _FM, _FM, _FM, _P]),
     "tdvc_sigmoid_f32": (_i, [_P, _P, _i64, _P]),
     "tdvc_sigmoid_backward_f32": (_i, [_P, _P, _i64, _P]),

@@ -272,6 +272,15 @@ def record_upsample2x(tape: Tape, x: FM, out: FM):
     tape.add(bwd)
 
 
+def record_resize_bilinear(tape: Tape, x: FM, out: FM, chscale):
+    """flownet.py:153-173: only the flow's resize back from the x32-padded size carries a gradient (the images are inputs)"""
+    def bwd():
+        if tape.needs_grad(x):
+            ops.resize_bilinear_backward(tape.grad(out), tape.grad(x), chscale)
+
+    tape.add(bwd)
+
+
 def record_spynet_level_input(tape: Tape, supp: FM, flow_lo, flow_up: FM, cat8: FM):
     tape.add(lambda: ops.spynet_level_input_backward(supp, flow_up, tape.grad(cat8), tape.grad(flow_up),
                                                      tape.grad(flow_lo) if flow_lo is not None else None))

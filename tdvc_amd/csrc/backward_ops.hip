@@ -361,6 +361,45 @@ __global__ void upsample2x_backward_kernel(FMap dy, FMap dx) {
   store8(dx, n, pix, c, acc);
 }
 
+// adjoint of resize_bilinear_kernel (pointwise.hip: bilinear, align_corners = False, arbitrary sizes, optional per-channel
+// scale): dx[iy][ix][c] += sum over the output pixels whose 2 x 2 source footprint contains (iy, ix) of wy * wx * chscale[c] *
+// dy[oy][ox][c], gathered per INPUT pixel (no atomics: reproducible).  Output row oy samples sy = rh (oy + 0.5) - 0.5 clamped
+// to >= 0 with rows y0 = min(floor(sy), H - 1), y1 = y0 + (y0 < H - 1): the candidates of input row iy are the oy with
+// sy in (iy - 1, iy + 1), plus the clamped borders.
+__global__ void resize_bilinear_backward_kernel(FMap dy, FMap dx, const float* chscale) {
+  const long npix = (long)dx.H * dx.W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * dx.N) return;
+  const int n = (int)(i / npix);
+  const long pix = i % npix;
+  const int iy = (int)(pix / dx.W), ix = (int)(pix % dx.W);
+  const float rh = (float)dx.H / (float)dy.H, rw = (float)dx.W / (float)dy.W;
+  // oy with rh (oy + 0.5) - 0.5 in [iy - 1, iy + 1]: a generous integer bracket, every candidate re-derives its exact weights
+  const int oy_lo = max(0, (int)floorf(((float)iy - 0.5f) / rh - 0.5f) - 1), oy_hi = min(dy.H - 1, (int)ceilf(((float)iy + 1.5f) / rh - 0.5f) + 1);
+  const int ox_lo = max(0, (int)floorf(((float)ix - 0.5f) / rw - 0.5f) - 1), ox_hi = min(dy.W - 1, (int)ceilf(((float)ix + 1.5f) / rw - 0.5f) + 1);
+  const float* gp = reinterpret_cast<const float*>(dy.p) + (long)n * dy.sn;
+  float* dp = reinterpret_cast<float*>(dx.p) + (long)n * dx.sn + pix * dx.sp;
+  for (int c = 0; c < dx.C; ++c) {
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      const float sy = fmaxf(rh * (oy + 0.5f) - 0.5f, 0.f);
+      const int y0 = (int)sy < dx.H - 1 ? (int)sy : dx.H - 1, y1 = y0 + (y0 < dx.H - 1);
+      const float ly1 = sy - y0;
+      const float wy = (y0 == iy ? 1.f - ly1 : 0.f) + (y1 == iy ? ly1 : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        const float sx = fmaxf(rw * (ox + 0.5f) - 0.5f, 0.f);
+        const int x0 = (int)sx < dx.W - 1 ? (int)sx : dx.W - 1, x1 = x0 + (x0 < dx.W - 1);
+        const float lx1 = sx - x0;
+        const float wx = (x0 == ix ? 1.f - lx1 : 0.f) + (x1 == ix ? lx1 : 0.f);
+        if (wx == 0.f) continue;
+        acc += wy * wx * gp[((long)oy * dy.W + ox) * dy.sp + c];
+      }
+    }
+    dp[c] += chscale ? acc * chscale[c] : acc;
+  }
+}
+
 // Backward of spynet_level_input_kernel, stage 1 (per full-resolution pixel): total gradient of the up-sampled flow
 //   dflow_up <- dflow_up (conv residual) + dcat8[6:8] (flow channels of the level input) + warp gradient
 // The warp is grid_sample(bilinear, border, align_corners=True): d/d(ix) of the bilinear sample, zero where the
@@ -853,6 +892,13 @@ extern "C" int tdvc_upsample2x_backward(const tdvc_fmap* dy, const tdvc_fmap* dx
   const long total = (long)dx->N * dx->H * dx->W * (dx->C / 8);
   hipLaunchKernelGGL(upsample2x_backward_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*dy), to_dev(*dx));
   return tdvc_launch_status("tdvc_upsample2x_backward");
+}
+
+extern "C" int tdvc_resize_bilinear_backward(const tdvc_fmap* dy, const tdvc_fmap* dx, const float* chscale, void* stream) {
+  TDVC_CHECK(dy && dx && fmap_ok32(*dy) && fmap_ok32(*dx) && dy->N == dx->N && dy->C == dx->C, "tdvc_resize_bilinear_backward: two fp32 fmaps of equal batch and channels expected");
+  const long total = (long)dx->N * dx->H * dx->W;
+  hipLaunchKernelGGL(resize_bilinear_backward_kernel, grid1d(total), dim3(EW_BLOCK), 0, ST(stream), to_dev(*dy), to_dev(*dx), chscale);
+  return tdvc_launch_status("tdvc_resize_bilinear_backward");
 }
 
 extern "C" int tdvc_spynet_level_input_backward(const tdvc_fmap* supp, const tdvc_fmap* flow_up, const tdvc_fmap* dcat8, const tdvc_fmap* dflow_up,

@@ -34,77 +34,119 @@ struct F32Extra {
   int total_px;
 };
 
+// MT x NT register blocking (round 3): a wave computes MT cout tiles x NT pixel groups of 32, so that one pair of operand
+// fragments feeds MT * NT MFMAs.  With one 32 x 32 tile per wave (round 2) every 8 MFMAs (512 matrix cycles) pulled 4 KB of
+// operands per wave from L1 / L2 -- 32 B per cycle and CU with the four SIMDs busy, the practical L2 -> CU rate: the kernel
+// sat on operand traffic at 0.54 of the fp32 matrix peak, not on the matrix pipe.  2 x 2 blocking halves the bytes per MFMA.
+template <int MT, int NT>
 __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvParams p, const F32Extra e) {
   __shared__ int tdy[TDVC_MAX_TAPS], tdx[TDVC_MAX_TAPS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, r = lane & 31;
   if (tid < p.ntaps) { tdy[tid] = p.tap_dy[tid]; tdx[tid] = p.tap_dx[tid]; }
   __syncthreads();
-  const int ct = blockIdx.y * 4 + wave;
-  if (ct >= e.cout_tiles) return;                       // wave-uniform; no barrier follows
+  // workgroup = 2 pixel blocks (NT * 32 pixels each) x 2 cout blocks (MT tiles each): waves 0,1 share the pixels, 0,2 the weights
+  const int ct0 = (blockIdx.y * 2 + (wave & 1)) * MT;
+  if (ct0 >= e.cout_tiles) return;                      // wave-uniform; no barrier follows
+  const int pb = blockIdx.x * 2 + (wave >> 1);
 
-  const int px = blockIdx.x * 32 + r;
-  const bool pv = px < e.total_px;
-  const int pxc = pv ? px : 0;
   const int hw = p.Ho * p.Wo;
-  const int n = pxc / hw, rem = pxc - n * hw;
-  const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-  const int iy0 = oy * p.in_stride - p.pad, ix0 = ox * p.in_stride - p.pad;
-  const float* xn = e.x + (long)n * p.x_sn;
+  bool pv[NT];
+  int pn[NT], poy[NT], pox[NT], iy0[NT], ix0[NT];
+  const float* xn[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int px = (pb * NT + nt) * 32 + r;
+    pv[nt] = px < e.total_px;
+    const int pxc = pv[nt] ? px : 0;
+    pn[nt] = pxc / hw;
+    const int rem = pxc - pn[nt] * hw;
+    poy[nt] = rem / p.Wo;
+    pox[nt] = rem - poy[nt] * p.Wo;
+    iy0[nt] = poy[nt] * p.in_stride - p.pad;
+    ix0[nt] = pox[nt] * p.in_stride - p.pad;
+    xn[nt] = e.x + (long)pn[nt] * p.x_sn;
+  }
+  if (!__builtin_amdgcn_readfirstlane(__ballot(pv[0]) != 0ull)) return;      // a pixel block past the end (wave-uniform)
 
   const int T = p.nchunks * p.steps;
   const int ck8 = e.ck8, CK = ck8 * 8, H2 = ck8 >> 1;
-  const float* wp = e.w + ((long)ct * T) * 512 + lane * 8;
+  const float* wp = e.w + ((long)ct0 * T) * 512 + lane * 8;      // tile ct0 + mt: + mt * T * 512
 
-  f32x16 acc;
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
-  // two k-steps per trip: four 32-byte operand loads are in flight before the first MFMA consumes one (the odd tail
-  // repeats the last k-step with a zeroed activation fragment)
-  for (int g2 = 0; g2 < T; g2 += 2) {
-    f32x8 a[2], b[2];
-    bool ok[2];
+  // software pipeline over k-steps: the operand fragments of step g + 1 (MT + NT loads of 32 bytes per lane) are in flight
+  // while the 8 * MT * NT MFMAs of step g run
+  f32x8 a[2][MT], b[2][NT];
+  auto fetch = [&](int g, f32x8 (&af)[MT], f32x8 (&bf)[NT]) {
+    const int gc = min(g, T - 1);
+    const int ch = gc / p.steps, s = gc - ch * p.steps;
+    int tap, cofs;
+    if (ck8 == 1) {
+      tap = min(2 * s + hh, p.ntaps - 1);               // the padded half step carries zero weights
+      cofs = ch * 8;
+    } else {
+      tap = s / H2;
+      cofs = ch * CK + (s - tap * H2) * 16 + hh * 8;
+    }
+    const int dy = tdy[tap], dx = tdx[tap];
+    const int cc = min(cofs, p.Cin - 8);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int g = min(g2 + u, T - 1);
-      const int ch = g / p.steps, s = g - ch * p.steps;
-      int tap, cofs;
-      if (ck8 == 1) {
-        tap = min(2 * s + hh, p.ntaps - 1);               // the padded half step carries zero weights
-        cofs = ch * 8;
-      } else {
-        tap = s / H2;
-        cofs = ch * CK + (s - tap * H2) * 16 + hh * 8;
-      }
-      const int iy = iy0 + tdy[tap], ix = ix0 + tdx[tap];
-      ok[u] = pv && g2 + u < T && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && cofs < p.Cin;
-      const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1), cc = min(cofs, p.Cin - 8);
-      const float* bp = xn + ((long)iyc * p.W + ixc) * p.x_sp + cc;
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
-      const float* ap = wp + (long)g * 512;
+    for (int mt = 0; mt < MT; ++mt) {
+      const float* ap = wp + ((long)mt * T + gc) * 512;
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap), a1 = *reinterpret_cast<const f32x4*>(ap + 4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { a[u][j] = a0[j]; a[u][4 + j] = a1[j]; b[u][j] = b0[j]; b[u][4 + j] = b1[j]; }
+      for (int j = 0; j < 4; ++j) { af[mt][j] = a0[j]; af[mt][4 + j] = a1[j]; }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int nt = 0; nt < NT; ++nt) {
+      const int iy = iy0[nt] + dy, ix = ix0[nt] + dx;
+      const bool ok = pv[nt] && g < T && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && cofs < p.Cin;
+      const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
+      const float* bp = xn[nt] + ((long)iyc * p.W + ixc) * p.x_sp + cc;
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float bv = ok[u] ? b[u][j] : 0.f;
-        if (p.square) bv = bv * bv;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][j], bv, acc, 0, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        float v0 = ok ? b0[j] : 0.f, v1 = ok ? b1[j] : 0.f;
+        if (p.square) { v0 *= v0; v1 *= v1; }
+        bf[nt][j] = v0; bf[nt][4 + j] = v1;
       }
     }
+  };
+  auto mfmas = [&](f32x8 (&af)[MT], f32x8 (&bf)[NT]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0);
+  };
+  fetch(0, a[0], b[0]);
+  for (int g = 0; g < T; g += 2) {
+    fetch(g + 1, a[1], b[1]);                           // g + 1 == T: a zeroed fragment (ok = false), harmless
+    mfmas(a[0], b[0]);
+    if (g + 2 < T) fetch(g + 2, a[0], b[0]);
+    if (g + 1 < T) mfmas(a[1], b[1]);
   }
 
-  if (!pv) return;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    float v[4];
+  for (int nt = 0; nt < NT; ++nt) {
+    if (!pv[nt]) continue;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = acc[4 * g + i];
-    convk::epilogue4<true>(p, n, oy, ox, ct * 32 + 8 * g + 4 * hh, v);
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[mt][nt][4 * g + i];
+        convk::epilogue4<true>(p, pn[nt], poy[nt], pox[nt], (ct0 + mt) * 32 + 8 * g + 4 * hh, v);
+      }
   }
 }
 
@@ -225,7 +267,16 @@ extern "C" int tdvc_conv2d_f32(const tdvc_conv_desc* d, void* stream) {
   e.ck8 = ck8;
   e.cout_tiles = cout_tiles32(d->cout);
   e.total_px = d->x.N * Ho * Wo;
-  const dim3 grid((unsigned)((e.total_px + 31) / 32), (unsigned)((e.cout_tiles + 3) / 4));
-  hipLaunchKernelGGL(conv_f32_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, e);
+  // workgroup = 2 x (NT * 32) pixels by 2 x MT cout tiles; small maps keep NT = 1 so that the few pixels still spread over the CUs
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool big = e.total_px >= 16384;
+  if (e.cout_tiles == 1) {
+    if (big) hipLaunchKernelGGL((conv_f32_kernel<1, 2>), dim3((unsigned)((e.total_px + 127) / 128), 1), dim3(256), 0, st, p, e);
+    else hipLaunchKernelGGL((conv_f32_kernel<1, 1>), dim3((unsigned)((e.total_px + 63) / 64), 1), dim3(256), 0, st, p, e);
+  } else {
+    const unsigned gy = (unsigned)((e.cout_tiles + 3) / 4);
+    if (big) hipLaunchKernelGGL((conv_f32_kernel<2, 2>), dim3((unsigned)((e.total_px + 127) / 128), gy), dim3(256), 0, st, p, e);
+    else hipLaunchKernelGGL((conv_f32_kernel<2, 1>), dim3((unsigned)((e.total_px + 63) / 64), gy), dim3(256), 0, st, p, e);
+  }
   return tdvc_launch_status("tdvc_conv2d_f32");
 }

@@ -853,7 +853,14 @@ def resize_bilinear(x: FM, H: int, W: int, chscale: torch.Tensor | None = None) 
     dx, dy = x.desc(), out.desc()
     L.check(L.lib().tdvc_resize_bilinear(C.byref(dx), C.byref(dy), chscale.data_ptr() if chscale is not None else None,
                                          _stream()), "resize_bilinear")
+    _rec("resize_bilinear", x, out, chscale)
     return out
+
+
+def resize_bilinear_backward(dy: FM, dx: FM, chscale: torch.Tensor | None = None) -> None:
+    d1, d2 = dy.desc(), dx.desc()
+    L.check(L.lib().tdvc_resize_bilinear_backward(C.byref(d1), C.byref(d2), chscale.data_ptr() if chscale is not None else None, _stream()),
+            "resize_bilinear_backward")
 
 
 # ----------------------------------------------------------------------------- in-loop filter matching

@@ -482,3 +482,42 @@ def test_conv_c8_equals_direct_kernel(report):
     assert torch.equal(outs[0], outs[1])
     ref = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.01)
     assert_close(outs[0], ref, RT, AT, "conv_c8 vs torch", report)
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_gdn128_equals_conv_path(inverse, with_res, report):
+    """the one-pass GDN kernel (conv_gdn128: x read once, gamma in registers, norm rounded to fp16 like the conv path) against
+    the same call on conv_mfma_v5 (1x1 conv over x^2 + GDN epilogue): bit-equal, on a batch of two images whose pixel count
+    is not a multiple of the 32-pixel tile (tiles straddle rows and the image boundary) and on channel-slice views"""
+    import ctypes
+
+    from tdvc_amd import _lib
+    ops = _ops()
+    fn = _lib.lib().tdvc_debug_enable_gdn128
+    fn.argtypes = [ctypes.c_int]
+    fn.restype = None
+    C, H, W = 128, 95, 101
+    x = rnd16(randn(2, 2 * C, H, W, seed=71))
+    gamma = rnd16(torch.rand(C, C, generator=torch.Generator().manual_seed(72)) * 0.02 + 0.1 * torch.eye(C))
+    beta = torch.rand(C, generator=torch.Generator().manual_seed(73)) + 0.5
+    r = rnd16(randn(2, C, H, W, seed=74))
+    xf = to_fm(x, ops).ch(C, C)                              # a channel-slice view: pixel stride 2C
+    rf = to_fm(r, ops) if with_res else None
+    pc = ops.pack_conv(gamma.view(C, C, 1, 1), beta, stride=1, pad=0)
+    names, outs = [], []
+    try:
+        for on in (1, 0):
+            fn(on)
+            y = ops.conv(xf, pc, square=True, gdn=ops.GDN_INV if inverse else ops.GDN_FWD, aux=xf, res=rf)
+            names.append(ops.L.lib().tdvc_last_conv_kernel().decode())
+            outs.append(fm_to_cpu(y))
+    finally:
+        fn(1)
+    report(f"GDN inverse={inverse} res={with_res} @2x{H}x{W}: kernels {names}, max |diff| {float((outs[0] - outs[1]).abs().max()):.3e}")
+    assert names[0] == "gdn128" and names[1] != "gdn128"
+    assert torch.equal(outs[0], outs[1])
+    xs = x[:, C:]
+    norm = F.conv2d(rnd16(xs * xs), gamma.view(C, C, 1, 1), beta)
+    ref = xs * (torch.sqrt(norm) if inverse else torch.rsqrt(norm)) + (r if with_res else 0)
+    assert_close(outs[0], ref, 4e-3, 4e-3, f"gdn128 inverse={inverse}", report)

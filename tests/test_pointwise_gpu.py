@@ -187,3 +187,22 @@ def test_entropy_rate_terms(report):
     assert abs(float(bits) - bits_ref) <= 2e-4 * bits_ref + 1e-2
     yh = ops.quantize(to_fm(y, ops, C, torch.float32), ops.FM.empty(2, 9, 15, C))
     assert torch.equal(fm_to_cpu(yh), torch.round(y))
+
+
+@pytest.mark.parametrize("src,dst", [((64, 96), (57, 90)), ((30, 50), (32, 64)), ((96, 64), (90, 61))])
+def test_resize_bilinear_backward(src, dst, report):
+    """adjoint of resize_bilinear (flownet.py:153-173: the flow's way back from the x32-padded size, with the per-channel
+    W/Wu, H/Hu rescale) against torch autograd of F.interpolate(bilinear, align_corners=False), down- and up-scaling"""
+    ops = _ops()
+    (h, w), (H, W) = src, dst
+    fl = randn(2, 2, h, w, seed=91)
+    g = randn(2, 2, H, W, seed=92)
+    sc = torch.tensor([W / w, H / h], dtype=torch.float32)
+    x = fl.clone().requires_grad_(True)
+    (F.interpolate(x, size=(H, W), mode="bilinear", align_corners=False) * sc.view(1, 2, 1, 1) * g).sum().backward()
+    dx = ops.FM.zeros(2, h, w, 2, dtype=torch.float32)
+    ops.resize_bilinear_backward(to_fm(g, ops, 2, torch.float32), dx, sc.cuda())
+    assert_close(fm_to_cpu(dx), x.grad, 1e-5, 1e-5, f"resize_bilinear backward {src}->{dst}", report)
+    # accumulation: a second call adds
+    ops.resize_bilinear_backward(to_fm(g, ops, 2, torch.float32), dx, sc.cuda())
+    assert_close(fm_to_cpu(dx), 2 * x.grad, 2e-5, 2e-5, "resize_bilinear backward accumulates", report)
