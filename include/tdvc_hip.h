@@ -75,6 +75,12 @@ typedef struct {
                              A 3x3 stride-2 pad-1 conv becomes a 2x2 stride-1 conv (kh=kw=2, pad=1 on the
                              top/left only) over that view; weights are packed for the virtual conv
                              (tdvc_amd/ops.py::pack_conv(s2d=True)).  Needs H, W even and C % 32 == 0. */
+  int32_t bcast_T;        /* ABI 3.  > 0: the conv result b (1x1, stride 1, cout == y.C == 64, no activation / residual / GDN) is not
+                             stored but broadcast-added over the bcast_T channel slices of width y.C that start at y:
+                             y[:, t] = lrelu(y[:, t] + b), in place (y's pixel stride covers the slices) -- Bottleneck3D's temporal
+                             conv + `out + temporal` + LeakyReLU (pnet.py:304-314) as ONE pass over the 4-frame buffer.  The conv
+                             input may be channels of the same buffer (a 1x1 conv reads only the pixels it then overwrites). */
+  float bcast_slope;
 } tdvc_conv_desc;
 
 /* ---------------------------------------------------------------- library */

@@ -30,7 +30,8 @@ class ConvDesc(C.Structure):
                 ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
                 ("ck", C.c_int32), ("square_input", C.c_int32), ("gdn", C.c_int32),
                 ("aux", FMapDesc), ("act", C.c_int32), ("slope", C.c_float),
-                ("round_before_act", C.c_int32), ("res", FMapDesc), ("res2", FMapDesc), ("out_mode", C.c_int32), ("s2d", C.c_int32)]
+                ("round_before_act", C.c_int32), ("res", FMapDesc), ("res2", FMapDesc), ("out_mode", C.c_int32), ("s2d", C.c_int32),
+                ("bcast_T", C.c_int32), ("bcast_slope", C.c_float)]
 
 
 class DcnDesc(C.Structure):

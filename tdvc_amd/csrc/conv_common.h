@@ -17,6 +17,7 @@ struct ConvParams {
   int simple;           // host decision: transposed fast epilogue (conv_is_simple)
   int s2d, Corig;       // space-to-depth view of a stride-2 conv (v3 only): Corig = channels per parity
   int reverse;          // walk the tile raster backwards (alternate launches: see tdvc_conv2d, "Infinity Cache")
+  int bcast_T; float bcast_slope;   // conv_mfma_v5 only: y[:, t] = lrelu(y[:, t] + conv) over bcast_T slices (tdvc_conv_desc::bcast_T)
   int8_t tap_dy[TDVC_MAX_TAPS], tap_dx[TDVC_MAX_TAPS];
 };
 
@@ -279,7 +280,10 @@ __device__ __forceinline__ void epilogue_store_row(const ConvParams& p, const Pa
 // 32 accumulators (+ bias) -> packed fp16 (v_cvt_pk_f16_f32), activation as packed fp16 math (what the reference's
 // autocast computes: the conv result is an fp16 tensor and ReLU / LeakyReLU runs on it), 8 ds_write_b64, 4
 // ds_read_b128, packed fp16 residual adds, 4 full-line stores: ~90 vector instructions.
-template <int NTX, bool BIAS_IN_ACC>
+// BCAST (conv_mfma_v5, tdvc_conv_desc::bcast_T == 4): the row is not stored; it is added to the four 64-channel slices that
+// start at y and LeakyReLU'd in place, with the arithmetic of bcast_add_act_kernel (fp32 add of the two fp16 values,
+// v > 0 ? v : v * slope, one rounding) -- bit-identical to the conv followed by tdvc_bcast_add_act.
+template <int NTX, bool BIAS_IN_ACC, bool BCAST = false>
 __device__ __forceinline__ void epilogue_lean_seq(const ConvParams& p, f32x16 (&acc)[2][NTX], const float* bias64, unsigned char* ew, int n,
                                                   int cbase, int oy_first, int ox_first, int lane, bool zero_acc, bool full) {
   constexpr int EPS = 144;
@@ -346,6 +350,27 @@ __device__ __forceinline__ void epilogue_lean_seq(const ConvParams& p, f32x16 (&
         const half4 o = {lo[0], lo[1], hi[0], hi[1]};
         *reinterpret_cast<half4*>(ew + r * EPS + (mt * 32 + 8 * g + 4 * hh) * 2) = o;
       }
+    if constexpr (BCAST) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const half8 v = *reinterpret_cast<const half8*>(ew + (k * 8 + prow) * EPS + chunk * 16);
+        half_t* yp = yb + (long)opix[k] * p.y.sp;
+        half8 xs[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xs[t] = *reinterpret_cast<const half8*>(yp + t * 64);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          half8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float s = (float)xs[t][j] + (float)v[j];
+            o[j] = (half_t)(s > 0.f ? s : s * p.bcast_slope);
+          }
+          if (ok[k]) *reinterpret_cast<half8*>(yp + t * 64) = o;
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       half8 v = *reinterpret_cast<const half8*>(ew + (k * 8 + prow) * EPS + chunk * 16);

@@ -212,7 +212,7 @@ extern "C" int tdvc_conv2d_f32(const tdvc_conv_desc* d, void* stream) {
   TDVC_CHECK(d->ntaps >= 1 && d->ntaps <= TDVC_MAX_TAPS && d->kh >= 1 && d->kh <= 7 && d->kw >= 1 && d->kw <= 7,
              "tdvc_conv2d_f32: bad kernel %dx%d ntaps=%d", d->kh, d->kw, d->ntaps);
   TDVC_CHECK(d->ck == 8 || d->ck == 16 || d->ck == 32 || d->ck == 64, "tdvc_conv2d_f32: bad ck %d", d->ck);
-  TDVC_CHECK(d->cout >= 1 && !d->s2d && !d->round_before_act, "tdvc_conv2d_f32: cout / s2d / round16 not supported in the fp32 form");
+  TDVC_CHECK(d->cout >= 1 && !d->s2d && !d->round_before_act && !d->bcast_T, "tdvc_conv2d_f32: cout / s2d / round16 / bcast_T not supported in the fp32 form");
   for (int t = 0; t < d->ntaps; ++t)
     TDVC_CHECK(d->tap_dy[t] >= 0 && d->tap_dy[t] < d->kh && d->tap_dx[t] >= 0 && d->tap_dx[t] < d->kw,
                "tdvc_conv2d_f32: tap %d out of the %dx%d window", t, d->kh, d->kw);

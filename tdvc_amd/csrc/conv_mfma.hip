@@ -356,6 +356,7 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
   p.in_stride = d->stride;
   const int ck8 = d->ck / 8;
   p.s2d = d->s2d; p.Corig = d->x.C;
+  p.bcast_T = d->bcast_T; p.bcast_slope = d->bcast_slope;
   p.nchunks = d->s2d ? (4 * d->x.C) / d->ck : (d->x.C + d->ck - 1) / d->ck;
   p.steps = (d->ntaps * ck8 + 1) / 2;
   p.square = d->square_input; p.gdn = d->gdn; p.act = d->act; p.slope = d->slope;
@@ -373,6 +374,17 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   auto chose = [](const char* name) { snprintf(g_last_kernel, sizeof(g_last_kernel), "%s", name); };
+  if (d->bcast_T) {          // temporal 1x1 conv + broadcast add + LeakyReLU over the slices at y: one kernel takes it (conv_mfma_v5)
+    TDVC_CHECK(d->bcast_T == 4 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->cout == 64 && d->y.C == 64 && d->y.sp >= 4 * 64 &&
+                   d->y.dtype == TDVC_F16 && d->out_mode == TDVC_OUT_NHWC && d->act == TDVC_ACT_NONE && !d->gdn && !d->res.p && !d->res2.p &&
+                   !d->square_input && !d->round_before_act && d->bias && d->bcast_slope >= 0.f && d->bcast_slope <= 1.f && conv_v5_eligible(d, Ho, Wo) &&
+                   convk::conv_is_lean(p),
+               "tdvc_conv2d: bcast_T needs a plain 1x1 / stride 1 conv to 64 channels of >= 8192 pixels, y a 64-channel window of a buffer with >= 4 slices, bcast_T == 4");
+    p.simple = 2;
+    p.slope = 1.f;
+    chose("conv_mfma_v5(bcast)");
+    return launch_conv_v5(p, 1, d->x.N, st);
+  }
   if (d->s2d) {
     TDVC_CHECK(conv_v3_eligible(d, Ho, Wo), "tdvc_conv2d: s2d conv not eligible for the stage-pipelined kernel");
     chose("conv_mfma_v3(s2d)");

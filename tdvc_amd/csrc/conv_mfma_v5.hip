@@ -155,7 +155,11 @@ __global__ __launch_bounds__(NTHR5, 1) void conv_mfma_v5_kernel(const ConvParams
       const int tile = p.reverse ? e.nbtiles - 1 - (first + tile_i * stride) : first + tile_i * stride;
       const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
       const int oy0 = ty * (WR * NWAVE) + wave * WR;
-      if constexpr (SIMPLE) {
+      if constexpr (SIMPLE == 4) {
+        // lean + broadcast-add over the four slices at y (tdvc_conv_desc::bcast_T): the wave overwrites exactly the pixels whose
+        // input channels it has finished reading (1x1: no halo; the prefetched stages belong to other pixels)
+        convk::epilogue_lean_seq<WR, false, true>(p, acc, bias_s, tbuf, n, cb * 64, oy0, tx * TW5, lane, true, false);
+      } else if constexpr (SIMPLE) {
         // the private tile doubles as the transpose scratch (this wave's reads of it are complete:
         // every fragment read was waited for before its MFMA)
         convk::epilogue_simple_rows<WR, false, SIMPLE>(p, acc, bias_s, tbuf, n, cb * 64, oy0, tx * TW5, lane, true);
@@ -202,10 +206,13 @@ int launch_tl(const ConvParams& q, const V5Extra& e, int mode, dim3 grid, int ld
       err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v5_kernel<2, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err == hipSuccess)
       err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v5_kernel<0, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (err == hipSuccess)
+      err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v5_kernel<4, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err != hipSuccess) { tdvc_set_error("conv v5: hipFuncSetAttribute failed: %s", hipGetErrorString(err)); return (int)err; }
     attr_done = true;
   }
-  if (mode == 2) hipLaunchKernelGGL((conv_mfma_v5_kernel<2, TL>), grid, dim3(NTHR5), lds, st, q, e);
+  if (mode == 4) hipLaunchKernelGGL((conv_mfma_v5_kernel<4, TL>), grid, dim3(NTHR5), lds, st, q, e);
+  else if (mode == 2) hipLaunchKernelGGL((conv_mfma_v5_kernel<2, TL>), grid, dim3(NTHR5), lds, st, q, e);
   else if (mode == 1) hipLaunchKernelGGL((conv_mfma_v5_kernel<1, TL>), grid, dim3(NTHR5), lds, st, q, e);
   else hipLaunchKernelGGL((conv_mfma_v5_kernel<0, TL>), grid, dim3(NTHR5), lds, st, q, e);
   return tdvc_launch_status("tdvc_conv2d(v5)");
@@ -240,7 +247,7 @@ int launch_conv_v5(const ConvParams& p, int cout_blocks, int N, hipStream_t st) 
   if (gx > e.nbtiles) gx = e.nbtiles;
   dim3 grid(gx, cout_blocks, N);
   const int tl = v5_tl(p.kh, p.kw);
-  if (tl == 4) return launch_tl<4>(q, e, simple ? (convk::conv_is_lean(p) ? 2 : 1) : 0, grid, lds, st);
+  if (tl == 4) return launch_tl<4>(q, e, p.bcast_T ? 4 : (simple ? (convk::conv_is_lean(p) ? 2 : 1) : 0), grid, lds, st);
   tdvc_set_error("conv v5: unsupported window %dx%d", p.kh, p.kw);
   return TDVC_EINVAL;
 }

@@ -113,6 +113,27 @@ def subpel_conv3x3(cin, cout, r=1):
 LR = dict(act=ACT_LRELU, slope=0.01)
 STREAM_ORDERS = ("raster", "wavefront")
 
+# host range coding off the critical path (compress(defer=True), VideoCompressor.encode): the coder library releases the GIL
+_RANS_POOL = None
+
+
+def _rans_pool():
+    global _RANS_POOL
+    if _RANS_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _RANS_POOL = ThreadPoolExecutor(max_workers=2, thread_name_prefix="tdvc-rans")
+    return _RANS_POOL
+
+
+class PendingStrings:
+    """the byte strings of a compress(defer=True) call: `result()` -> [y_strings, z_strings] once the worker threads are done"""
+
+    def __init__(self, y_futs, z_strings):
+        self._y, self._z = y_futs, z_strings
+
+    def result(self):
+        return [[f.result() for f in self._y], self._z]
+
 
 class ResidualBlock(nn.Module, PackCache):
     def __init__(self, cin, cout):
@@ -497,10 +518,31 @@ class Cheng2020Anchor(nn.Module, PackCache):
                 steps.append(ps)
         return steps
 
+    def _ar_setup(self, H, W, adt, dev, B):
+        """per (grid, dtype): the wavefront position list, the step sizes, the staging chain and pinned host buffers for the
+        symbols / indexes of B images -- built once (the position list alone is 2 ms of Python at 68 x 120)"""
+        cache = self.__dict__.setdefault("_ar_cache", {})
+        key = (H, W, adt, str(dev), B)
+        c = cache.get(key)
+        if c is None:
+            steps = self.wavefront_steps(H, W)
+            flat = torch.tensor([p for st in steps for p in st], dtype=torch.int32, device=dev)
+            c = dict(flat=flat, fl=flat.long(), sizes=np.array([len(st) for st in steps], dtype=np.int32), chain=self._ar_chain(H, adt, dev),
+                     host=[(torch.empty((H * W, self.M), dtype=torch.int32).pin_memory(), torch.empty((H * W, self.M), dtype=torch.int32).pin_memory())
+                           for _ in range(B)])
+            cache.clear()                # one geometry at a time (the staging buffers are not small)
+            cache[key] = c
+        return c
+
     @torch.no_grad()
-    def compress(self, x: FM, f32=False, order="raster"):
+    def compress(self, x: FM, f32=False, order="raster", defer=False):
         """-> {"strings": [y_strings, z_strings], "shape": (h, w)} like compressai's compress()
         (`f32`: the fp32-island mode, see run()).
+
+        `defer`: "strings" is a PendingStrings instead: the symbols leave the device asynchronously into pinned memory and the
+        host range coder runs on a worker thread while the caller goes on enqueueing GPU work (VideoCompressor.encode: the
+        coder's 5.5 ms per million symbols disappear from the frame's critical path); `result()` joins.  At most one deferred
+        call per coder may be outstanding (its pinned buffers are re-used by the next call).
 
         `order`: symbol order of the y stream.  "raster" is compressai's (h, w, c) order: the stream the reference writes, decoded
         position by position.  "wavefront" emits the same symbols anti-diagonal by anti-diagonal (the order the encoder computes
@@ -525,25 +567,35 @@ class Cheng2020Anchor(nn.Module, PackCache):
         zs = zsym.permute(0, 3, 1, 2).contiguous().cpu().numpy()                   # compressai order (C, h, w)
         zidx = np.broadcast_to(np.arange(M, dtype=np.int32)[:, None, None], zs.shape[1:])
         z_strings = [ops.rans_encode(zs[b], zidx, ebt) for b in range(B)]
-        steps = self.wavefront_steps(H, W)
-        flat = torch.tensor([p for st in steps for p in st], dtype=torch.int32, device=dev)
-        sizes = np.array([len(st) for st in steps], dtype=np.int32)
-        chain = self._ar_chain(H, adt, dev)
-        y_strings, dbg = [], []
+        st = self._ar_setup(H, W, adt, dev, B)
+        flat, sizes, chain, fl = st["flat"], st["sizes"], st["chain"], st["fl"]
+        y_jobs, dbg = [], []
         for b in range(B):
-            y_hat = FM.zeros(1, H, W, M, dtype=adt, device=dev)
-            sym = torch.zeros((H, W, M), dtype=torch.int32, device=dev)
-            idx = torch.zeros((H, W, M), dtype=torch.int32, device=dev)
+            # every position is written exactly once and only causal (already written) neighbours are read: no zero fill
+            y_hat = FM.empty(1, H, W, M, dtype=adt, device=dev)
+            sym = torch.empty((H, W, M), dtype=torch.int32, device=dev)
+            idx = torch.empty((H, W, M), dtype=torch.int32, device=dev)
             # the W + 3(H-1) steps run natively (tdvc_ar_wavefront: gather -> context conv -> entropy_parameters -> quantise)
             ops.ar_wavefront(None, None, y32.batch(b, 1), y_hat, params.batch(b, 1), chain["x1"], chain["pc"], chain["descs"], chain["gp"],
                              flat, sizes, M, W, table, idx, sym)
+            hs, hi = st["host"][b]
             if order == "wavefront":
-                fl = flat.long()
-                y_strings.append(ops.rans_encode(sym[fl[:, 0], fl[:, 1]].cpu().numpy(), idx[fl[:, 0], fl[:, 1]].cpu().numpy(), gct))
+                hs.copy_(sym[fl[:, 0], fl[:, 1]], non_blocking=True)
+                hi.copy_(idx[fl[:, 0], fl[:, 1]], non_blocking=True)
             else:
-                y_strings.append(ops.rans_encode(sym.cpu().numpy(), idx.cpu().numpy(), gct))  # raster (h, w, c) order
+                hs.copy_(sym.view(H * W, M), non_blocking=True)                # raster (h, w, c) order
+                hi.copy_(idx.view(H * W, M), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+
+            def job(ev=ev, hs=hs, hi=hi):
+                ev.synchronize()
+                return ops.rans_encode(hs.numpy(), hi.numpy(), gct)
+            y_jobs.append(_rans_pool().submit(job) if defer else job())
             dbg.append({"y_hat": y_hat, "symbols": sym, "indexes": idx})
-        return {"strings": [y_strings, z_strings], "shape": (z.H, z.W), "_debug": dbg}
+        if defer:
+            return {"strings": PendingStrings(y_jobs, z_strings), "shape": (z.H, z.W), "_debug": dbg}
+        return {"strings": [y_jobs, z_strings], "shape": (z.H, z.W), "_debug": dbg}
 
     @torch.no_grad()
     def decompress(self, strings, shape, synth=True, f32=False, order="raster"):

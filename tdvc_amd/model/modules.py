@@ -299,6 +299,7 @@ class Bottleneck3D(nn.Module):
 
 
 LOOPFILTER_PAIR = True          # A/B switch (tools/ab_infer.py): layer1.conv1 + spatial_conv3d as one tdvc_conv_pair launch
+LOOPFILTER_BCAST = True         # A/B switch: temporal conv + broadcast add + LeakyReLU as one conv_mfma_v5 launch (bcast_T)
 
 
 class LoopFilter(nn.Module, PackCache):
@@ -359,10 +360,15 @@ class LoopFilter(nn.Module, PackCache):
         else:
             self._slices("b1", l1.conv1, a, bf, **lr)
             self._slices("bs", l1.spatial_conv3d, bf, s)
-        tm = ops.conv(s.ch(0, 192), pk_conv(self, "bt", l1.temporal_conv3d))
-        if ops.TAPE is not None:
-            s = ops.clone(s)          # `s` itself is the temporal conv's input: keep it for the backward pass
-        ops.bcast_add_act(s, tm, 4, 0.1)
+        if ops.TAPE is None and LOOPFILTER_BCAST and B * H * W >= 8192:
+            # inference: temporal (3,1,1) conv over frames 0-2 + `out + temporal` + LeakyReLU (pnet.py:304-314) as ONE pass over
+            # the 4-frame buffer: a wave computes the 64 temporal channels of its pixels and rewrites their four slices in place
+            ops.conv(s.ch(0, 192), pk_conv(self, "bt", l1.temporal_conv3d), out=s.ch(0, 64), bcast_T=4, bcast_slope=0.1)
+        else:
+            tm = ops.conv(s.ch(0, 192), pk_conv(self, "bt", l1.temporal_conv3d))
+            if ops.TAPE is not None:
+                s = ops.clone(s)          # `s` itself is the temporal conv's input: keep it for the backward pass
+            ops.bcast_add_act(s, tm, 4, 0.1)
         # inference re-uses `bf` for the block output; under the tape `bf` is still needed by the backward of `bs`
         o = bf if ops.TAPE is None else FM.empty(B, H, W, 256, device=dev)
         self._slices("b3", l1.conv3, s, o, res_buf=a)

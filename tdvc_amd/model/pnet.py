@@ -50,6 +50,7 @@ class VideoCompressor(nn.Module):
         for m in self.modules():
             m.__dict__.pop("_packed", None)
             m.__dict__.pop("_tables", None)         # host copies of the coder CDF tables (Cheng2020Anchor._coder_tables)
+            m.__dict__.pop("_ar_cache", None)       # wavefront-loop descriptors point at the packed weights
 
     def load_state_dict(self, *a, **kw):
         r = super().load_state_dict(*a, **kw)
@@ -170,18 +171,18 @@ class VideoCompressor(nn.Module):
         self.mvCoder.update()
         self.resCoder.update()
         f32 = self.coder_fp32
-        mv = self.mvCoder.compress(estmv, f32=f32, order=self.stream_order)
+        mv = self.mvCoder.compress(estmv, f32=f32, order=self.stream_order, defer=True)       # range coding on worker threads
         cat = lambda dbg: FM(torch.cat([d["y_hat"].t for d in dbg], 0))
         out = {}
 
         def res_y_hat(pred):
             resid = ops.scale_act_res(f_cur, FM.empty(B, H, W, 64, device=dev), res=pred, res_sign=-1.0)
-            out["res"] = self.resCoder.compress(resid, f32=f32, order=self.stream_order)
+            out["res"] = self.resCoder.compress(resid, f32=f32, order=self.stream_order, defer=True)
             return cat(out["res"]["_debug"])
         recon = self._reconstruct(cat(mv["_debug"]), res_y_hat, feats, refs8, iframe8)
         rs = out["res"]
-        return {"strings": [mv["strings"][0], mv["strings"][1], rs["strings"][0], rs["strings"][1]],
-                "shapes": [mv["shape"], rs["shape"]], "recon": recon}
+        mvs, rss = mv["strings"].result(), rs["strings"].result()                     # join the range coders
+        return {"strings": [mvs[0], mvs[1], rss[0], rss[1]], "shapes": [mv["shape"], rs["shape"]], "recon": recon}
 
     @torch.no_grad()
     def decode(self, strings, shapes, refer_frames):

@@ -360,7 +360,7 @@ def _plain_form(pc: PackedConv) -> PackedConv:
 
 def conv_desc(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, res: FM | None = None,
               res2: FM | None = None, gdn=GDN_NONE, aux: FM | None = None, square=False, out_dtype=None,
-              round16=False, nchw_out: torch.Tensor | None = None):
+              round16=False, nchw_out: torch.Tensor | None = None, bcast_T=0, bcast_slope=0.0):
     """the `tdvc_conv_desc` a conv() call would launch, without launching it (native loops re-launch fixed descriptors:
     `tdvc_ar_decode_serial`).  -> (descriptor, result FM / tensor, Ho, Wo, layer form used, layer as recorded)
 
@@ -393,6 +393,7 @@ def conv_desc(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=
     d.res = res.desc() if res is not None else _NULL_FM
     d.res2 = res2.desc() if res2 is not None else _NULL_FM
     d.s2d = int(pc.s2d)
+    d.bcast_T, d.bcast_slope = int(bcast_T), float(bcast_slope)
     if nchw_out is not None:
         assert nchw_out.shape == (x.N, pc.cout, Ho, Wo) and nchw_out.dtype == torch.float32 and nchw_out.is_contiguous()
         d.out_mode = OUT_NCHW_F32
@@ -415,10 +416,14 @@ def conv_desc(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=
 
 def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, res: FM | None = None,
          res2: FM | None = None, gdn=GDN_NONE, aux: FM | None = None, square=False, out_dtype=None,
-         round16=False, nchw_out: torch.Tensor | None = None) -> FM | torch.Tensor:
-    d, ret, Ho, Wo, pc, rec_pc = conv_desc(x, pc, out, act, slope, res, res2, gdn, aux, square, out_dtype, round16, nchw_out)
+         round16=False, nchw_out: torch.Tensor | None = None, bcast_T=0, bcast_slope=0.0) -> FM | torch.Tensor:
+    """`bcast_T` (inference only): the conv result is not stored but broadcast-added, with LeakyReLU(bcast_slope), over the
+    bcast_T channel slices that start at `out` (tdvc_conv_desc::bcast_T)"""
+    d, ret, Ho, Wo, pc, rec_pc = conv_desc(x, pc, out, act, slope, res, res2, gdn, aux, square, out_dtype, round16, nchw_out, bcast_T, bcast_slope)
     if x.f32 and TAPE is not None and not _IN_BACKWARD:
         raise L.TdvcHipError("conv: the fp32 form has no backward (the fp32 islands are an inference / coding mode)")
+    if bcast_T and TAPE is not None and not _IN_BACKWARD:
+        raise L.TdvcHipError("conv: bcast_T is an inference-only fusion (under the tape use conv + bcast_add_act)")
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

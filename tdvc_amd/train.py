@@ -26,6 +26,7 @@ def refresh_packed(model: torch.nn.Module) -> None:
     """after an optimizer step: every packed layer follows its (in-place updated) parameters"""
     pcs = []
     for m in model.modules():
+        m.__dict__.pop("_ar_cache", None)            # coder: cached wavefront-loop descriptors (their fp32 weight twins are re-created)
         if hasattr(m, "refresh_packed"):
             m.refresh_packed()                       # GDN (effective gamma / beta), EntropyBottleneck (packed table)
             continue

@@ -521,3 +521,27 @@ def test_gdn128_equals_conv_path(inverse, with_res, report):
     norm = F.conv2d(rnd16(xs * xs), gamma.view(C, C, 1, 1), beta)
     ref = xs * (torch.sqrt(norm) if inverse else torch.rsqrt(norm)) + (r if with_res else 0)
     assert_close(outs[0], ref, 4e-3, 4e-3, f"gdn128 inverse={inverse}", report)
+
+
+def test_conv_bcast_add_act_fused(report):
+    """Bottleneck3D's temporal conv + broadcast add + LeakyReLU (pnet.py:304-314) as one launch (tdvc_conv_desc::bcast_T on
+    conv_mfma_v5) against the two-launch form (1x1 conv, then tdvc_bcast_add_act): bit-equal, in place over a 4-slice buffer,
+    ragged tile edges, batch 2"""
+    ops = _ops()
+    B, H, W = 2, 90, 101
+    s0 = rnd16(randn(B, 256, H, W, seed=81))
+    w = rnd16(randn(64, 192, 1, 1, seed=82) * 0.07)
+    pc = ops.pack_conv(w, None, stride=1, pad=0)
+    a = to_fm(s0, ops)
+    tm = ops.conv(a.ch(0, 192), pc)
+    ops.bcast_add_act(a, tm, 4, 0.1)
+    b = to_fm(s0, ops)
+    ops.conv(b.ch(0, 192), pc, out=b.ch(0, 64), bcast_T=4, bcast_slope=0.1)
+    name = ops.L.lib().tdvc_last_conv_kernel().decode()
+    ga, gb = fm_to_cpu(a), fm_to_cpu(b)
+    report(f"temporal conv + broadcast add fused: kernel {name}, max |diff| vs two launches {float((ga - gb).abs().max()):.3e}")
+    assert name == "conv_mfma_v5(bcast)"
+    assert torch.equal(ga, gb)
+    t = F.conv2d(s0[:, :192], w)
+    ref = torch.cat([F.leaky_relu(s0[:, 64 * k:64 * k + 64] + rnd16(t), 0.1) for k in range(4)], 1)
+    assert_close(gb, ref, RT, AT, "fused temporal conv + broadcast add", report)
