@@ -81,10 +81,14 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvParams p, const
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
-  // software pipeline over k-steps: the operand fragments of step g + 1 (MT + NT loads of 32 bytes per lane) are in flight
-  // while the 8 * MT * NT MFMAs of step g run
-  f32x8 a[2][MT], b[2][NT];
-  auto fetch = [&](int g, f32x8 (&af)[MT], f32x8 (&bf)[NT]) {
+  // software pipeline over k-steps: the operand fragments of step g + 1 (MT + NT loads of 32 bytes per lane) are ISSUED before
+  // the 8 * MT * NT MFMAs of step g and consumed after them.  fetch() only issues loads and derives the zeroing multiplier; every
+  // use of a loaded register (the multiplier, the square) sits in mfmas(), and sched_barrier(0) pins the order load / matrix /
+  // load / matrix -- left to itself hipcc sank the loads behind `ok ? x : 0` branches (round 2) or regrouped the two sets so
+  // that every k-step waited vmcnt(0) for the loads it had just issued (first round-3 build): 0.5 of the fp32 matrix peak.
+  f32x4 a[2][MT][2], b[2][NT][2];
+  float bm[2][NT];
+  auto fetch = [&](int g, f32x4 (&af)[MT][2], f32x4 (&bf)[NT][2], float (&mk)[NT]) {
     const int gc = min(g, T - 1);
     const int ch = gc / p.steps, s = gc - ch * p.steps;
     int tap, cofs;
@@ -100,39 +104,51 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvParams p, const
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const float* ap = wp + ((long)mt * T + gc) * 512;
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap), a1 = *reinterpret_cast<const f32x4*>(ap + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { af[mt][j] = a0[j]; af[mt][4 + j] = a1[j]; }
+      af[mt][0] = *reinterpret_cast<const f32x4*>(ap);
+      af[mt][1] = *reinterpret_cast<const f32x4*>(ap + 4);
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int iy = iy0[nt] + dy, ix = ix0[nt] + dx;
-      const bool ok = pv[nt] && g < T && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && cofs < p.Cin;
+      const bool ok = (int)pv[nt] & (int)(g < T) & (int)(iy >= 0) & (int)(iy < p.H) & (int)(ix >= 0) & (int)(ix < p.W) & (int)(cofs < p.Cin);   // no short-circuit branches
       const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
       const float* bp = xn[nt] + ((long)iyc * p.W + ixc) * p.x_sp + cc;
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float v0 = ok ? b0[j] : 0.f, v1 = ok ? b1[j] : 0.f;
-        if (p.square) { v0 *= v0; v1 *= v1; }
-        bf[nt][j] = v0; bf[nt][4 + j] = v1;
-      }
+      bf[nt][0] = *reinterpret_cast<const f32x4*>(bp);
+      bf[nt][1] = *reinterpret_cast<const f32x4*>(bp + 4);
+      // out-of-image taps are zeroed by an OPAQUE multiplier, not by a select (x * 1.0f is exact; the clamped address always
+      // holds a finite in-image value)
+      float m = ok ? 1.f : 0.f;
+      asm volatile("" : "+v"(m));
+      mk[nt] = m;
     }
   };
-  auto mfmas = [&](f32x8 (&af)[MT], f32x8 (&bf)[NT]) {
+  auto mfmas = [&](f32x4 (&af)[MT][2], f32x4 (&bf)[NT][2], float (&mk)[NT]) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int j = 0; j < 4; ++j) {
+        float bv[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) {
+          bv[nt] = bf[nt][h2][j] * mk[nt];
+          if (p.square) bv[nt] *= bv[nt];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][h2][j], bv[nt], acc[mt][nt], 0, 0, 0);
+      }
   };
-  fetch(0, a[0], b[0]);
+  fetch(0, a[0], b[0], bm[0]);
   for (int g = 0; g < T; g += 2) {
-    fetch(g + 1, a[1], b[1]);                           // g + 1 == T: a zeroed fragment (ok = false), harmless
-    mfmas(a[0], b[0]);
-    if (g + 2 < T) fetch(g + 2, a[0], b[0]);
-    if (g + 1 < T) mfmas(a[1], b[1]);
+    fetch(g + 1, a[1], b[1], bm[1]);                    // g + 1 == T: a zeroed fragment (multiplier 0), harmless
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(a[0], b[0], bm[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(g + 2, a[0], b[0], bm[0]);                    // unconditional (past the end: clamped addresses, multiplier 0): a load under
+    __builtin_amdgcn_sched_barrier(0);                  // a branch makes hipcc drain vmcnt(0) at the join
+    mfmas(a[1], b[1], bm[1]);                           // g + 1 == T (odd T): adds exact zeros
+    __builtin_amdgcn_sched_barrier(0);
   }
 
 #pragma unroll

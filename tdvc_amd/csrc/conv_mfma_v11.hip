@@ -55,7 +55,10 @@ static long long* g_stamp11 = nullptr;
 static int g_stamp11_cap = 0;
 static int g_v11_experiment = 0;     // diagnostic builds only (wrong results): 1 = no weight DMA, 2 = no DMA at all, 3 = one fragment read per group
 
-template <bool STAMP = false>
+// EARLY (A/B, tdvc_debug_set_v11_dma_early): the next stage's 10 DMA slots under matrix groups 0-2 (4 + 3 + 3) instead of two
+// per group under groups 0-4.  A compile-time switch: as a run-time branch both forms stayed live and the kernel, which sits
+// at the 256-VGPR limit, spilled 18 vector and 47 scalar registers (137 instead of 105 us per launch in the frame).
+template <bool STAMP = false, bool EARLY = false>
 __global__ __launch_bounds__(NTHR11, 1) void conv_mfma_v11_kernel(const ConvParams p, const V11Extra e, long long* stamps = nullptr, int stamp_cap = 0) {
   long long stv[16];
   if constexpr (STAMP) { for (int i = 0; i < 16; ++i) stv[i] = 0; }
@@ -217,9 +220,15 @@ __global__ __launch_bounds__(NTHR11, 1) void conv_mfma_v11_kernel(const ConvPara
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
       }
-      if (have_next && g < 5) {          // 10 DMA slots of the next stage, two per group
-        issue_one(2 * g, nbuf);
-        issue_one(2 * g + 1, nbuf);
+      if (have_next) {                   // 10 DMA slots of the next stage
+        if constexpr (EARLY) {             // 4 + 3 + 3 under the first three groups: the last piece has >= 3 groups (~2.3 k cycles) to land
+          if (g == 0) { issue_one(0, nbuf); issue_one(1, nbuf); issue_one(2, nbuf); issue_one(3, nbuf); }
+          if (g == 1) { issue_one(4, nbuf); issue_one(5, nbuf); issue_one(6, nbuf); }
+          if (g == 2) { issue_one(7, nbuf); issue_one(8, nbuf); issue_one(9, nbuf); }
+        } else if (g < 5) {                // two per group
+          issue_one(2 * g, nbuf);
+          issue_one(2 * g + 1, nbuf);
+        }
       }
     }
     ST11(3);
@@ -314,6 +323,8 @@ __global__ __launch_bounds__(NTHR11, 1) void conv_mfma_v11_kernel(const ConvPara
 extern "C" void tdvc_debug_set_stamp_buffer_v11(void* buf, int cap_blocks) { g_stamp11 = (long long*)buf; g_stamp11_cap = cap_blocks; }
 extern "C" void tdvc_debug_set_v11_experiment(int mode) { g_v11_experiment = mode; }
 
+static int g_v11_dma_early = 0;
+extern "C" void tdvc_debug_set_v11_dma_early(int on) { g_v11_dma_early = on; }
 static bool g_v11_enabled = true;
 // tests and A/B benchmarks switch the kernel off to send the same layers to conv_mfma_v3
 extern "C" void tdvc_debug_enable_conv_v11(int enable) { g_v11_enabled = enable != 0; }
@@ -352,13 +363,16 @@ int launch_conv_v11(const ConvParams& p, int cout_blocks, int N, hipStream_t st)
   dim3 grid(gx, cout_blocks, N);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v11_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v11_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err == hipSuccess)
-      err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v11_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v11_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (err == hipSuccess)
+      err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v11_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err != hipSuccess) { tdvc_set_error("conv v11: hipFuncSetAttribute failed: %s", hipGetErrorString(err)); return (int)err; }
     attr_done = true;
   }
-  if (g_stamp11) hipLaunchKernelGGL(conv_mfma_v11_kernel<true>, grid, dim3(NTHR11), LDS11, st, q, e, g_stamp11, g_stamp11_cap);
-  else hipLaunchKernelGGL(conv_mfma_v11_kernel<false>, grid, dim3(NTHR11), LDS11, st, q, e, (long long*)nullptr, 0);
+  if (g_stamp11) hipLaunchKernelGGL((conv_mfma_v11_kernel<true, false>), grid, dim3(NTHR11), LDS11, st, q, e, g_stamp11, g_stamp11_cap);
+  else if (g_v11_dma_early) hipLaunchKernelGGL((conv_mfma_v11_kernel<false, true>), grid, dim3(NTHR11), LDS11, st, q, e, (long long*)nullptr, 0);
+  else hipLaunchKernelGGL((conv_mfma_v11_kernel<false, false>), grid, dim3(NTHR11), LDS11, st, q, e, (long long*)nullptr, 0);
   return tdvc_launch_status("tdvc_conv2d(v11)");
 }
