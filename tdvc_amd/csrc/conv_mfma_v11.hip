@@ -55,10 +55,17 @@ static long long* g_stamp11 = nullptr;
 static int g_stamp11_cap = 0;
 static int g_v11_experiment = 0;     // diagnostic builds only (wrong results): 1 = no weight DMA, 2 = no DMA at all, 3 = one fragment read per group
 
-// EARLY (A/B, tdvc_debug_set_v11_dma_early): the next stage's 10 DMA slots under matrix groups 0-2 (4 + 3 + 3) instead of two
-// per group under groups 0-4.  A compile-time switch: as a run-time branch both forms stayed live and the kernel, which sits
-// at the 256-VGPR limit, spilled 18 vector and 47 scalar registers (137 instead of 105 us per launch in the frame).
-template <bool STAMP = false, bool EARLY = false>
+// Measured and dropped (round 3, tools/ab_v11.py, interleaved rounds in one process): the next stage's 10 DMA slots under matrix
+// groups 0-2 (4 + 3 + 3) instead of two per group under groups 0-4 -- 157.3 against 156.0 us at 128 -> 128 @544x960, 321 against
+// 311 us at 128 -> 64 @1088x1920: the stage-top wait is 130 of 8 500 cycles per stage, there is nothing to gain there.  As a
+// RUN-TIME switch the variant made this kernel, which sits at 247 of 256 VGPRs, spill 18 vector and 47 scalar registers (137
+// instead of 105 us per launch in the frame): switches in this kernel are template parameters.
+// Also measured and dropped (round 3): the hypothesis that both waves of a SIMD sit in their two LDS-DMA pieces at the end of
+// every matrix group TOGETHER (stamps: the matrix phase of a stage takes 7.9-8.3 k cycles for 4.6 k cycles of MFMA on the SIMD;
+// a piece costs its issuing wave 100-185 cycles).  Letting waves 4-7 issue their pieces in the MIDDLE of the group (after 6 of
+// its 12 MFMAs) was 2-3 % SLOWER on four layer shapes (162.3 against 158.3 us at 128 -> 128 @544x960): the asm statement in
+// the middle of the group splits the scheduling region and the pinned read / MFMA interleave degenerates into read pairs.
+template <bool STAMP = false>
 __global__ __launch_bounds__(NTHR11, 1) void conv_mfma_v11_kernel(const ConvParams p, const V11Extra e, long long* stamps = nullptr, int stamp_cap = 0) {
   long long stv[16];
   if constexpr (STAMP) { for (int i = 0; i < 16; ++i) stv[i] = 0; }
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(NTHR11, 1) void conv_mfma_v11_kernel(const ConvPara
     for (int g = 0; g < 6; ++g) {
       if (g + 1 < 6) load_group(g + 1, (g + 1) & 1);
 #pragma unroll
-      for (int ir = 0; ir < NT11 + 2; ++ir)
+      for (int ir = 0; ir < NT11 + 2; ++ir) {
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
           const int nt = ir - dy;
@@ -213,6 +220,7 @@ __global__ __launch_bounds__(NTHR11, 1) void conv_mfma_v11_kernel(const ConvPara
             acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][dy], fb[g & 1][ir], acc[nt], 0, 0, 0);
           }
         }
+      }
       if (g + 1 < 6) {                   // pin the software pipeline: the next group's 9 reads between this group's MFMAs
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
@@ -220,15 +228,9 @@ __global__ __launch_bounds__(NTHR11, 1) void conv_mfma_v11_kernel(const ConvPara
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
       }
-      if (have_next) {                   // 10 DMA slots of the next stage
-        if constexpr (EARLY) {             // 4 + 3 + 3 under the first three groups: the last piece has >= 3 groups (~2.3 k cycles) to land
-          if (g == 0) { issue_one(0, nbuf); issue_one(1, nbuf); issue_one(2, nbuf); issue_one(3, nbuf); }
-          if (g == 1) { issue_one(4, nbuf); issue_one(5, nbuf); issue_one(6, nbuf); }
-          if (g == 2) { issue_one(7, nbuf); issue_one(8, nbuf); issue_one(9, nbuf); }
-        } else if (g < 5) {                // two per group
-          issue_one(2 * g, nbuf);
-          issue_one(2 * g + 1, nbuf);
-        }
+      if (have_next && g < 5) {          // 10 DMA slots of the next stage, two per group
+        issue_one(2 * g, nbuf);
+        issue_one(2 * g + 1, nbuf);
       }
     }
     ST11(3);
@@ -323,8 +325,6 @@ __global__ __launch_bounds__(NTHR11, 1) void conv_mfma_v11_kernel(const ConvPara
 extern "C" void tdvc_debug_set_stamp_buffer_v11(void* buf, int cap_blocks) { g_stamp11 = (long long*)buf; g_stamp11_cap = cap_blocks; }
 extern "C" void tdvc_debug_set_v11_experiment(int mode) { g_v11_experiment = mode; }
 
-static int g_v11_dma_early = 0;
-extern "C" void tdvc_debug_set_v11_dma_early(int on) { g_v11_dma_early = on; }
 static bool g_v11_enabled = true;
 // tests and A/B benchmarks switch the kernel off to send the same layers to conv_mfma_v3
 extern "C" void tdvc_debug_enable_conv_v11(int enable) { g_v11_enabled = enable != 0; }
@@ -363,16 +363,13 @@ int launch_conv_v11(const ConvParams& p, int cout_blocks, int N, hipStream_t st)
   dim3 grid(gx, cout_blocks, N);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v11_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v11_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err == hipSuccess)
-      err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v11_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (err == hipSuccess)
-      err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v11_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v11_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err != hipSuccess) { tdvc_set_error("conv v11: hipFuncSetAttribute failed: %s", hipGetErrorString(err)); return (int)err; }
     attr_done = true;
   }
-  if (g_stamp11) hipLaunchKernelGGL((conv_mfma_v11_kernel<true, false>), grid, dim3(NTHR11), LDS11, st, q, e, g_stamp11, g_stamp11_cap);
-  else if (g_v11_dma_early) hipLaunchKernelGGL((conv_mfma_v11_kernel<false, true>), grid, dim3(NTHR11), LDS11, st, q, e, (long long*)nullptr, 0);
-  else hipLaunchKernelGGL((conv_mfma_v11_kernel<false, false>), grid, dim3(NTHR11), LDS11, st, q, e, (long long*)nullptr, 0);
+  if (g_stamp11) hipLaunchKernelGGL(conv_mfma_v11_kernel<true>, grid, dim3(NTHR11), LDS11, st, q, e, g_stamp11, g_stamp11_cap);
+  else hipLaunchKernelGGL(conv_mfma_v11_kernel<false>, grid, dim3(NTHR11), LDS11, st, q, e, (long long*)nullptr, 0);
   return tdvc_launch_status("tdvc_conv2d(v11)");
 }
