@@ -34,6 +34,8 @@ int launch_conv_v9(const ConvParams& p, int ck8, int cout_tiles32, int N, hipStr
 bool conv_v9_eligible(const tdvc_conv_desc* d, int Ho, int Wo, bool v3_ok);
 bool conv_c8_eligible(const tdvc_conv_desc* d, const ConvParams& p, int Ho, int Wo);
 int launch_conv_c8(const ConvParams& p, int N, hipStream_t st);
+bool conv_n16_eligible(const tdvc_conv_desc* d, int Ho, int Wo);
+int launch_conv_n16(const ConvParams& p, int N, hipStream_t st);
 bool gdn128_eligible(const tdvc_conv_desc* d, const ConvParams& p, int Ho, int Wo);
 int launch_gdn128(const ConvParams& p, int N, hipStream_t st);
 
@@ -394,6 +396,7 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
   if (gdn128_eligible(d, p, Ho, Wo)) { chose("gdn128"); return launch_gdn128(p, d->x.N, st); }
   if (conv_v5_eligible(d, Ho, Wo)) { chose("conv_mfma_v5"); return launch_conv_v5(p, tiles / 2, d->x.N, st); }
   if (conv_c8_eligible(d, p, Ho, Wo)) { chose("conv_c8"); return launch_conv_c8(p, d->x.N, st); }
+  if (conv_n16_eligible(d, Ho, Wo)) { chose("conv_n16"); return launch_conv_n16(p, d->x.N, st); }
   if (conv_v10_eligible(d, p, Ho, Wo)) { chose("conv_mfma_v10"); return launch_conv_v10(p, tiles / 2, d->x.N, st); }
   if (conv_v7_eligible(d, p, Ho, Wo)) { chose("conv_mfma_v7"); return launch_conv_v7(p, tiles / 2, d->x.N, st); }
   if (conv_v11_eligible(d, p, Ho, Wo)) { chose("conv_mfma_v11"); return launch_conv_v11(p, tiles / 2, d->x.N, st); }

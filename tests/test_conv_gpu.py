@@ -545,3 +545,67 @@ def test_conv_bcast_add_act_fused(report):
     t = F.conv2d(s0[:, :192], w)
     ref = torch.cat([F.leaky_relu(s0[:, 64 * k:64 * k + 64] + rnd16(t), 0.1) for k in range(4)], 1)
     assert_close(gb, ref, RT, AT, "fused temporal conv + broadcast add", report)
+
+
+N16_CASES = [
+    # name, N, cin, cout, k, H, W: the few-output-channel layers at >= 8192 output pixels (conv_n16: 16-row MFMA tiles)
+    ("n16_7x7_8_32", 1, 8, 32, 7, 90, 140),        # SPyNet basic module, first conv: two cout blocks, four taps per k-step
+    ("n16_7x7_32_16", 2, 32, 16, 7, 70, 130),      # one tap per k-step, ragged tile edges, batch 2
+    ("n16_3x3_64_16", 1, 64, 16, 3, 96, 96),       # half a tap per k-step
+    ("n16_3x3_8_24", 1, 8, 24, 3, 100, 90),        # four taps per k-step, 9 taps (a padded half step and a k-step past the last tap), 24 of 32 channels
+    ("n16_3x3_16_8", 1, 16, 8, 3, 90, 100),        # two taps per k-step
+]
+
+
+@pytest.mark.parametrize("case", N16_CASES, ids=[c[0] for c in N16_CASES])
+def test_conv_n16(case, report):
+    import ctypes
+
+    from tdvc_amd import _lib
+    ops = _ops()
+    name, N, cin, cout, k, H, W = case
+    fn = _lib.lib().tdvc_debug_enable_conv_n16
+    fn.argtypes = [ctypes.c_int]
+    fn.restype = None
+    x = rnd16(randn(N, cin, H, W, seed=51))
+    w = rnd16(randn(cout, cin, k, k, seed=52) * (1.0 / (cin * k * k) ** 0.5))
+    b = randn(cout, seed=53) * 0.1
+    ref = F.relu(F.conv2d(x, w, b, padding=k // 2))
+    pc = ops.pack_conv(w, b, stride=1, pad=k // 2)
+    xf = to_fm(x, ops)
+    names, outs = [], []
+    try:
+        for on in (1, 0):
+            fn(on)
+            y = ops.conv(xf, pc, act=ops.ACT_RELU)
+            names.append(ops.L.lib().tdvc_last_conv_kernel().decode())
+            outs.append(fm_to_cpu(y))
+    finally:
+        fn(1)
+    report(f"{name}: kernels {names}, max |n16 - direct| {float((outs[0] - outs[1]).abs().max()):.3e}")
+    assert names[0] == "conv_n16" and names[1] != "conv_n16"
+    assert_close(outs[0][:, :cout], ref, RT, AT, f"conv_n16 {name}", report)
+    if outs[0].shape[1] > cout:      # padded channels must be exactly zero (they feed the next layer)
+        assert float(outs[0][:, cout:].abs().max()) == 0.0
+
+
+def test_conv_n16_flow_head_and_featdown(report):
+    """the two heads at sizes the few-channel kernel takes: SPyNet's 7x7 16 -> 2 with fp32 output + fp32 residual
+    (flownet.py:227 + the flow update) and FeatureFix.featdown 3x3 64 -> 3, clamp, planar fp32 (pnet.py:262)"""
+    ops = _ops()
+    x = rnd16(randn(1, 16, 80, 120, seed=25))
+    w = rnd16(randn(2, 16, 7, 7, seed=26) * 0.05)
+    b = randn(2, seed=27) * 0.1
+    up = randn(1, 2, 80, 120, seed=28)
+    ref = F.conv2d(x, w, b, padding=3) + up
+    y = ops.conv(to_fm(x, ops), ops.pack_conv(w, b, stride=1, pad=3), res=to_fm(up, ops, Cpad=2, dtype=torch.float32), out_dtype=torch.float32)
+    assert ops.L.lib().tdvc_last_conv_kernel() == b"conv_n16" and y.f32 and y.C == 2
+    assert_close(fm_to_cpu(y), ref, 1e-4, 1e-4, "conv_n16 7x7 16->2 fp32 out + fp32 residual", report)
+    x = rnd16(randn(2, 64, 70, 100, seed=29))
+    w = rnd16(randn(3, 64, 3, 3, seed=30) * 0.1)
+    b = torch.tensor([0.5, 0.4, 0.6])
+    ref = F.conv2d(x, w, b, padding=1).clamp(0, 1)
+    out = torch.empty(2, 3, 70, 100, device="cuda")
+    ops.conv(to_fm(x, ops), ops.pack_conv(w, b, stride=1, pad=1), act=ops.ACT_CLAMP01, nchw_out=out)
+    assert ops.L.lib().tdvc_last_conv_kernel() == b"conv_n16"
+    assert_close(out.cpu(), ref, 1e-4, 1e-4, "conv_n16 featdown NCHW fp32 + clamp", report)
