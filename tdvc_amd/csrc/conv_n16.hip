@@ -12,14 +12,17 @@
 //     four taps of 8 -- the k-group of a lane picks its own tap;
 //   * ALL weights of the layer sit in LDS ([k-step][cout block][lane][8], <= 50 KB), gathered once per workgroup straight from
 //     the standard packed blob (a 16x16x32 A fragment is four 16-byte pieces of 32x32x16 fragments there: no second packing);
-//   * persistent workgroups walk 8 x 64-pixel tiles; a wave owns two rows: per k-step 1 A read + 8 B reads feed 8 MFMAs.
+//   * persistent workgroups of 8 waves walk 8 x 64-pixel tiles, a wave owns one row: per k-step 1 A read + 4 B reads feed 4
+//     MFMAs (x 2 cout blocks); the fragments of k-step S + 1 are read under the MFMAs of step S (the first version read, waited
+//     and multiplied step by step with 4 waves per CU: latency-bound, SLOWER than the padded direct kernel);
+//   * dense kh x kw windows only: a lane derives its tap's tile offset arithmetically (no table look-up in the loop).
 #include "conv_common.h"
 
 using convk::ConvParams;
 
 namespace {
 
-constexpr int N16_TH = 8, N16_TW = 64, N16_NR = 2, N16_NTHR = 256;
+constexpr int N16_TH = 8, N16_TW = 64, N16_NTHR = 512;     // 8 waves, one output row of 64 pixels each
 
 struct N16Extra {
   int ksteps;          // 32-wide k-steps = ceil(ntaps * cin / 32)
@@ -32,8 +35,7 @@ struct N16Extra {
 template <int NCB>     // cout blocks of 16
 __global__ __launch_bounds__(N16_NTHR, 1) void conv_n16_kernel(const ConvParams p, const N16Extra e) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  int* tapoff = reinterpret_cast<int*>(smem);                       // [49]
-  unsigned char* wl = smem + 256;                                    // [kstep][cb][lane 64][16 B]
+  unsigned char* wl = smem;                                          // [kstep][cb][lane 64][16 B]
   unsigned char* tile = wl + e.a_bytes;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -41,7 +43,6 @@ __global__ __launch_bounds__(N16_NTHR, 1) void conv_n16_kernel(const ConvParams 
   const int TIW = N16_TW + p.kw - 1, TIH = N16_TH + p.kh - 1;
   const int cin = p.Cin, c8n = cin >> 3;
 
-  if (tid < p.ntaps) tapoff[tid] = (p.tap_dy[tid] * TIW + p.tap_dx[tid]) * e.ps;
   // A fragments: 16x16x32 lane (row = l & 15, k = 8 (l >> 4) + j) of k-step S = old 32x32x16 lane (16 cb + row) + 32 h of step s,
   // 2 s + h = 4 S + (l >> 4)
   for (int i = tid; i < e.ksteps * NCB * 64; i += N16_NTHR) {
@@ -52,9 +53,16 @@ __global__ __launch_bounds__(N16_NTHR, 1) void conv_n16_kernel(const ConvParams 
     *reinterpret_cast<half8*>(wl + (long)i * 16) = v;
   }
 
-  int base[N16_NR];
-#pragma unroll
-  for (int r = 0; r < N16_NR; ++r) base[r] = ((wave * N16_NR + r) * TIW + px) * e.ps;
+  const int base = (wave * TIW + px) * e.ps;                         // this wave's row, this lane's pixel of column block 0
+  const int cstep = 16 * e.ps;
+  // the tile offset of the lane's tap in k-step S (dense window: tap t = (t / kw, t % kw); past the last tap the weights are
+  // zero and any in-tile address will do)
+  auto frag_off = [&](int S) {
+    const int kk0 = 32 * S + 8 * kg;
+    const int tap = min(kk0 >> e.cin_shift, p.ntaps - 1);
+    const int dy = tap / p.kw, dx = tap - dy * p.kw;
+    return base + (dy * TIW + dx) * e.ps + (kk0 & (cin - 1)) * 2;
+  };
 
   for (int tile_i = blockIdx.x; tile_i < e.ntiles; tile_i += gridDim.x) {
     const int per_img = e.tiles_x * ((p.Ho + N16_TH - 1) / N16_TH);
@@ -62,25 +70,30 @@ __global__ __launch_bounds__(N16_NTHR, 1) void conv_n16_kernel(const ConvParams 
     const int ty = rem / e.tiles_x, tx = rem - ty * e.tiles_x;
     const half_t* xn = p.x + (long)n * p.x_sn;
     const int iy0 = ty * N16_TH - p.pad, ix0 = tx * N16_TW - p.pad;
-    __syncthreads();                                                 // everyone is done with the previous tile (and, first time, nothing)
-    // ---- stage the halo tile: all of a thread's loads in flight at once
+    __syncthreads();                                                 // everyone is done with the previous tile
+    // ---- stage the halo tile: eight 16-byte loads of a thread in flight at once
     const int total = TIH * TIW * c8n;
-    for (int idx0 = tid; idx0 < total; idx0 += 4 * N16_NTHR) {
-      half8 v[4];
+    for (int idx0 = tid; idx0 < total; idx0 += 8 * N16_NTHR) {
+      half8 v[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const int idx = idx0 + u * N16_NTHR;
         const int pix = idx >> (e.cin_shift - 3), c8 = idx & (c8n - 1);
         const int rr = pix / TIW, cc = pix - rr * TIW;
         const int iy = iy0 + rr, ix = ix0 + cc;
-        const bool ok = idx < total && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const bool ok = (int)(idx < total) & (int)(iy >= 0) & (int)(iy < p.H) & (int)(ix >= 0) & (int)(ix < p.W);
         const half_t* src = xn + ((long)(ok ? iy : 0) * p.W + (ok ? ix : 0)) * p.x_sp + c8 * 8;
-        const half8 ld = *reinterpret_cast<const half8*>(src);
-        const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        v[u] = ok ? ld : z;
+        // unconditional load at a clamped address, zeroed by an OPAQUE bit mask: given `ok ? load : 0` hipcc sinks the load into a
+        // branch and waits for it there (conv_f32.hip has the measurement)
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 bits = *reinterpret_cast<const u32x4*>(src);
+        unsigned m = ok ? 0xFFFFFFFFu : 0u;
+        asm volatile("" : "+v"(m));
+        bits &= m;
+        v[u] = __builtin_bit_cast(half8, bits);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const int idx = idx0 + u * N16_NTHR;
         if (idx < total) {
           const int pix = idx >> (e.cin_shift - 3), c8 = idx & (c8n - 1);
@@ -90,44 +103,45 @@ __global__ __launch_bounds__(N16_NTHR, 1) void conv_n16_kernel(const ConvParams 
     }
     __syncthreads();
 
-    f32x4 acc[NCB][N16_NR][4];
+    f32x4 acc[NCB][4];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-      for (int r = 0; r < N16_NR; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[cb][r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < 4; ++c) acc[cb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int S = 0; S < e.ksteps; ++S) {
-      const int kk0 = 32 * S + 8 * kg;                               // this lane's 8 k values: one tap, 8 consecutive channels
-      const int tap = min(kk0 >> e.cin_shift, p.ntaps - 1);          // past the last tap: zero weights, any in-tile address will do
-      const int toff = tapoff[tap] + (kk0 & (cin - 1)) * 2;
-      half8 a[NCB];
+    half8 a0[NCB], b0[4], a1[NCB], b1[4];
+    auto load = [&](int S, half8 (&a)[NCB], half8 (&b)[4]) {
+      const int off = frag_off(S);
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) a[cb] = *reinterpret_cast<const half8*>(wl + ((S * NCB + cb) * 64 + lane) * 16);
 #pragma unroll
-      for (int r = 0; r < N16_NR; ++r)
+      for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const half8*>(tile + off + c * cstep);
+    };
+    auto mm = [&](half8 (&a)[NCB], half8 (&b)[4]) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const half8 b = *reinterpret_cast<const half8*>(tile + base[r] + c * 16 * e.ps + toff);
+      for (int c = 0; c < 4; ++c)
 #pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) acc[cb][r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cb], b, acc[cb][r][c], 0, 0, 0);
-        }
+        for (int cb = 0; cb < NCB; ++cb) acc[cb][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cb], b[c], acc[cb][c], 0, 0, 0);
+    };
+    const int KS = e.ksteps;
+    load(0, a0, b0);
+    for (int S = 0; S < KS; S += 2) {                                // fragments of the next k-step are read under this step's MFMAs
+      load(min(S + 1, KS - 1), a1, b1);
+      mm(a0, b0);
+      load(min(S + 2, KS - 1), a0, b0);
+      if (S + 1 < KS) mm(a1, b1);
     }
 
     // ---- epilogue: lane = (pixel px, output channels 16 cb + 4 kg .. + 3)
+    const int oy = ty * N16_TH + wave;
 #pragma unroll
-    for (int r = 0; r < N16_NR; ++r) {
-      const int oy = ty * N16_TH + wave * N16_NR + r;
+    for (int c = 0; c < 4; ++c) {
+      const int ox = tx * N16_TW + 16 * c + px;
+      if (oy < p.Ho && ox < p.Wo) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int ox = tx * N16_TW + 16 * c + px;
-        if (oy < p.Ho && ox < p.Wo) {
-#pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) {
-            float v[4] = {acc[cb][r][c][0], acc[cb][r][c][1], acc[cb][r][c][2], acc[cb][r][c][3]};
-            convk::epilogue4(p, n, oy, ox, 16 * cb + 4 * kg, v);
-          }
+        for (int cb = 0; cb < NCB; ++cb) {
+          float v[4] = {acc[cb][c][0], acc[cb][c][1], acc[cb][c][2], acc[cb][c][3]};
+          convk::epilogue4(p, n, oy, ox, 16 * cb + 4 * kg, v);
         }
       }
     }
@@ -137,7 +151,7 @@ __global__ __launch_bounds__(N16_NTHR, 1) void conv_n16_kernel(const ConvParams 
 inline int n16_ps(int cin) { return 2 * cin + 16; }
 inline int n16_ksteps(int ntaps, int cin) { return (ntaps * cin + 31) / 32; }
 inline int n16_lds(int cin, int kh, int kw, int ntaps, int ncb) {
-  return 256 + n16_ksteps(ntaps, cin) * ncb * 1024 + (N16_TH + kh - 1) * (N16_TW + kw - 1) * n16_ps(cin);
+  return n16_ksteps(ntaps, cin) * ncb * 1024 + (N16_TH + kh - 1) * (N16_TW + kw - 1) * n16_ps(cin);
 }
 
 }  // namespace
@@ -152,7 +166,9 @@ bool conv_n16_eligible(const tdvc_conv_desc* d, int Ho, int Wo) {
   const int cin = d->x.C;
   const bool cin_ok = cin == 8 || cin == 16 || cin == 32 || cin == 64;
   // a single channel chunk (ck == cin): the packed blob's k order is then the flattened (tap, channel) order this kernel walks
-  return cin_ok && d->ck == cin && d->stride == 1 && d->cout <= 32 && !d->s2d && !d->square_input && !d->gdn && (long)Ho * Wo >= 8192 &&
+  bool dense = d->ntaps == d->kh * d->kw;                        // the kernel derives (dy, dx) from the tap index
+  for (int t = 0; dense && t < d->ntaps; ++t) dense = d->tap_dy[t] == t / d->kw && d->tap_dx[t] == t % d->kw;
+  return cin_ok && dense && d->ck == cin && d->stride == 1 && d->cout <= 32 && !d->s2d && !d->square_input && !d->gdn && (long)Ho * Wo >= 8192 &&
          n16_lds(cin, d->kh, d->kw, d->ntaps, d->cout <= 16 ? 1 : 2) <= 150 * 1024;
 }
 
@@ -166,7 +182,7 @@ int launch_conv_n16(const ConvParams& p, int N, hipStream_t st) {
   e.ntiles = N * e.tiles_x * ((p.Ho + N16_TH - 1) / N16_TH);
   e.cin_shift = p.Cin == 8 ? 3 : p.Cin == 16 ? 4 : p.Cin == 32 ? 5 : 6;
   const int lds = n16_lds(p.Cin, p.kh, p.kw, p.ntaps, ncb);
-  const int per_cu = lds <= 78 * 1024 ? 2 : 1;
+  const int per_cu = lds <= 78 * 1024 ? 2 : 1;     // 16 or 8 waves per CU
   int grid = e.ntiles < 256 * per_cu ? e.ntiles : 256 * per_cu;
   auto go = [&](auto kern) -> int {
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
