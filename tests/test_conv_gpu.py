@@ -601,11 +601,11 @@ def test_conv_n16_flow_head_and_featdown(report):
     y = ops.conv(to_fm(x, ops), ops.pack_conv(w, b, stride=1, pad=3), res=to_fm(up, ops, Cpad=2, dtype=torch.float32), out_dtype=torch.float32)
     assert ops.L.lib().tdvc_last_conv_kernel() == b"conv_n16" and y.f32 and y.C == 2
     assert_close(fm_to_cpu(y), ref, 1e-4, 1e-4, "conv_n16 7x7 16->2 fp32 out + fp32 residual", report)
-    x = rnd16(randn(2, 64, 70, 100, seed=29))
+    x = rnd16(randn(2, 64, 90, 100, seed=29))
     w = rnd16(randn(3, 64, 3, 3, seed=30) * 0.1)
     b = torch.tensor([0.5, 0.4, 0.6])
     ref = F.conv2d(x, w, b, padding=1).clamp(0, 1)
-    out = torch.empty(2, 3, 70, 100, device="cuda")
+    out = torch.empty(2, 3, 90, 100, device="cuda")
     ops.conv(to_fm(x, ops), ops.pack_conv(w, b, stride=1, pad=1), act=ops.ACT_CLAMP01, nchw_out=out)
     assert ops.L.lib().tdvc_last_conv_kernel() == b"conv_n16"
     assert_close(out.cpu(), ref, 1e-4, 1e-4, "conv_n16 featdown NCHW fp32 + clamp", report)
