@@ -8,6 +8,8 @@
 // (2) tdvc_dcn_v2_forward_f32: fp32 NCHW operator with `_ext.dcn_v2_forward` semantics.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 struct DcnParams {
@@ -166,6 +168,250 @@ __global__ __launch_bounds__(256) void dcn_fused_kernel(const DcnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// dcn_lds: the same operator with the bilinear corners gathered from an LDS window instead of L1.
+//
+// dcn_fused_kernel is bound by the texture path: 4 corners x 9 taps x 8 groups of 16 bytes per pixel, every one a cache
+// line of its own for the L1 (profiles/r01_dcn_fused_1080p_pmc.txt), behind two barriers per three taps.  Here
+//   * a workgroup owns an 8 x 16 pixel tile and stages the (8+12) x (16+12) window of x around it in LDS once (80 KB for
+//     the 64-channel map, row pitch 32 pixels, 16-byte group slots XOR-swizzled by the column so that the 16 lanes of one
+//     ds_read_b128 phase -- neighbouring pixels, same group -- fall on 16 different slots);
+//   * the sampling lane IS the MFMA B lane: wave w owns rows 2w, 2w+1 of the tile (32 pixels = the 32 columns of a
+//     32x32x16 product), lane (r, hh) samples group 2*s2 + hh of pixel r at k-step (tap, s2), i.e. exactly its 8 k-values
+//     of the B fragment: no column tile, no barrier between sampling and the matrix product;
+//   * offsets / masks of the tile travel through the same LDS region first (coalesced 16-byte loads of the 432-byte
+//     per-pixel record), each lane keeps its 4 groups x 9 taps in registers;
+//   * a sample whose corners leave the window (more than 5 px from the tile's mean displacement) falls back to the global gather, per lane; a wave whose
+//     lanes are all inside (the common case) takes a branch without it.
+// Arithmetic and accumulation order are those of dcn_fused_kernel: the two kernels agree bit for bit
+// (tests/test_dcn_gpu.py).
+// ------------------------------------------------------------------------------------------
+constexpr int DL_TY = 8, DL_TX = 16, DL_M = 6;
+constexpr int DL_WH = DL_TY + 2 * DL_M, DL_WW = DL_TX + 2 * DL_M, DL_WP = 32;      // window rows, columns, row pitch (pixels)
+constexpr int DL_LDS = DL_WH * DL_WP * 128;                                           // 81,920 B: two workgroups per CU
+constexpr int DL_OM_REC = 27 * 8 * 2;                                                 // 432 B of offsets + masks per pixel
+constexpr int DL_RED = ((DL_WH - 1) * DL_WP + DL_WW) * 128;                           // pitch padding of the last row: never a window pixel
+static_assert(DL_TY * DL_TX * DL_OM_REC <= DL_RED, "the offset/mask tile is staged through the window region, below the reduction scratch");
+static_assert(DL_WP >= DL_WW + 1 && DL_WP % 16 == 0, "row pitch: a multiple of 16 pixels keeps the two rows of a wave on disjoint slots");
+
+struct DlSample {            // one (pixel, group, tap) sample in flight: corner weights, LDS addresses, image coordinates
+  float w1, w2, w3, w4;
+  int s00, s01, s10, s11;    // LDS byte offsets of the four corners (clamped into the window)
+  int y0, y1, x0, x1;        // image coordinates (for the fallback gather)
+  bool iw;                   // all four corners inside the window
+};
+
+__device__ __forceinline__ DlSample dl_prepare(int wy0, int wx0, int g, int H, int W, float h_im, float w_im, float mask) {
+  // identical arithmetic to sample8_bf; only the source of the four corner vectors differs
+  DlSample q;
+  const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+  const float hc = fminf(fmaxf(h_im, -2.f), (float)H + 1.f), wc = fminf(fmaxf(w_im, -2.f), (float)W + 1.f);
+  const float hf = floorf(hc), wf = floorf(wc);
+  const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
+  const float lh = hc - hf, lw = wc - wf, hh = 1.f - lh, hw = 1.f - lw;
+  const bool hl = h_low >= 0 && h_low <= H - 1, hhg = h_high >= 0 && h_high <= H - 1;
+  const bool wl = w_low >= 0 && w_low <= W - 1, whg = w_high >= 0 && w_high <= W - 1;
+  q.w1 = (inside && hl && wl) ? hh * hw * mask : 0.f; q.w2 = (inside && hl && whg) ? hh * lw * mask : 0.f;
+  q.w3 = (inside && hhg && wl) ? lh * hw * mask : 0.f; q.w4 = (inside && hhg && whg) ? lh * lw * mask : 0.f;
+  q.y0 = min(max(h_low, 0), H - 1); q.y1 = min(max(h_high, 0), H - 1);
+  q.x0 = min(max(w_low, 0), W - 1); q.x1 = min(max(w_high, 0), W - 1);
+  const int a0 = q.y0 - wy0, a1 = q.y1 - wy0, b0 = q.x0 - wx0, b1 = q.x1 - wx0;  // window coordinates (a1 >= a0, b1 >= b0)
+  q.iw = a0 >= 0 && a1 < DL_WH && b0 >= 0 && b1 < DL_WW;
+  const int ca0 = q.iw ? a0 : 0, ca1 = q.iw ? a1 : 0, cb0 = q.iw ? b0 : 0, cb1 = q.iw ? b1 : 0;
+  const int r0 = ca0 * (DL_WP * 128), r1 = ca1 * (DL_WP * 128);
+  const int c0 = cb0 * 128 + ((g ^ ((cb0 >> 1) & 7)) << 4), c1 = cb1 * 128 + ((g ^ ((cb1 >> 1) & 7)) << 4);
+  q.s00 = r0 + c0; q.s01 = r0 + c1; q.s10 = r1 + c0; q.s11 = r1 + c1;
+  return q;
+}
+
+// The same for a tile whose whole window lies inside the image: a sample inside the window needs none of the image-border
+// logic (every corner exists, the clamps are identities), so the common path is floor / fractions / four products and the
+// addresses.  The window test is done on the floats (NaN fails it); a lane that fails is recomputed by dl_prepare.
+__device__ __forceinline__ DlSample dl_prepare_interior(int wy0, int wx0, int g, float h_im, float w_im, float mask) {
+  DlSample q;
+  const float hf = floorf(h_im), wf = floorf(w_im);
+  q.iw = hf >= (float)wy0 && hf <= (float)(wy0 + DL_WH - 2) && wf >= (float)wx0 && wf <= (float)(wx0 + DL_WW - 2);
+  const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+  q.w1 = hh * hw * mask; q.w2 = hh * lw * mask; q.w3 = lh * hw * mask; q.w4 = lh * lw * mask;
+  const int a0 = q.iw ? (int)hf - wy0 : 0, b0 = q.iw ? (int)wf - wx0 : 0, b1 = b0 + 1;
+  const int r0 = a0 * (DL_WP * 128);
+  const int c0 = b0 * 128 + ((g ^ ((b0 >> 1) & 7)) << 4), c1 = b1 * 128 + ((g ^ ((b1 >> 1) & 7)) << 4);
+  q.s00 = r0 + c0; q.s01 = r0 + c1; q.s10 = q.s00 + DL_WP * 128; q.s11 = q.s01 + DL_WP * 128;
+  q.y0 = q.y1 = q.x0 = q.x1 = 0;
+  return q;
+}
+
+__global__ __launch_bounds__(256, 2) void dcn_lds_kernel(const DcnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char win[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, r = lane & 31;
+  const int tiles_x = (p.W + DL_TX - 1) / DL_TX;
+  const int tile_id = tdvc_xcd_tile(blockIdx.x);
+  const int tx = tile_id % tiles_x, ty = tile_id / tiles_x;
+  const int n = blockIdx.y;
+  const half_t* xn = p.x + (long)n * p.x_sn;
+
+  // ---- phase 1: the tile's offset / mask records -> LDS -> registers
+  {
+    const half_t* omn = p.om + (long)n * p.om_sn;
+    constexpr int PIECES = DL_TY * DL_TX * 27;                    // 3456 16-byte pieces, 13.5 per thread
+#pragma unroll
+    for (int k0 = 0; k0 < 14; k0 += 7) {
+      half8 v[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const int i = min(tid + (k0 + k) * 256, PIECES - 1);
+        const int pl = i / 27, pc = i - pl * 27;
+        const int cy = min(ty * DL_TY + (pl >> 4), p.H - 1), cx = min(tx * DL_TX + (pl & 15), p.W - 1);
+        v[k] = *reinterpret_cast<const half8*>(omn + ((long)cy * p.W + cx) * p.om_sp + pc * 8);
+      }
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const int i = min(tid + (k0 + k) * 256, PIECES - 1);      // the clamped duplicates rewrite the last piece with itself
+        *reinterpret_cast<half8*>(win + i * 16) = v[k];
+      }
+    }
+  }
+  __syncthreads();
+  const int pl = (2 * wave + (r >> 4)) * DL_TX + (r & 15);
+  const int oy = ty * DL_TY + 2 * wave + (r >> 4), ox = tx * DL_TX + (r & 15);
+  half2v off[4][9];
+  float msk[4][9];
+  float sdy = 0.f, sdx = 0.f;
+#pragma unroll
+  for (int s2 = 0; s2 < 4; ++s2) {
+    const int g = 2 * s2 + hh;
+    const unsigned char* rec = win + pl * DL_OM_REC;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      off[s2][t] = *reinterpret_cast<const half2v*>(rec + g * 36 + 4 * t);
+      const half_t m = *reinterpret_cast<const half_t*>(rec + 288 + g * 18 + 2 * t);
+      msk[s2][t] = __builtin_amdgcn_rcpf(1.f + __expf(-(float)m));
+      sdy += __builtin_amdgcn_fmed3f((float)off[s2][t][0], -64.f, 64.f);      // a stray wild offset must not move the window
+      sdx += __builtin_amdgcn_fmed3f((float)off[s2][t][1], -64.f, 64.f);
+    }
+  }
+  // the window is centred on the tile's mean displacement (coherent motion moves the window, not the samples out of it);
+  // the choice only decides which samples take the fallback gather, never a value
+#pragma unroll
+  for (int sh = 32; sh >= 1; sh >>= 1) {
+    sdy += __shfl_xor(sdy, sh);
+    sdx += __shfl_xor(sdx, sh);
+  }
+  float* red = reinterpret_cast<float*>(win + DL_RED);
+  if (lane == 0) { red[2 * wave] = sdy; red[2 * wave + 1] = sdx; }
+  __syncthreads();
+  const float inv = 1.f / (float)(DL_TY * DL_TX * 72);
+  const int cy = __builtin_amdgcn_readfirstlane((int)rintf(fminf(fmaxf((red[0] + red[2] + red[4] + red[6]) * inv, -4096.f), 4096.f)));
+  const int cx = __builtin_amdgcn_readfirstlane((int)rintf(fminf(fmaxf((red[1] + red[3] + red[5] + red[7]) * inv, -4096.f), 4096.f)));
+
+  // ---- phase 2: the window of x -> LDS (swizzled)
+  const int wy0 = ty * DL_TY - DL_M + cy, wx0 = tx * DL_TX - DL_M + cx;
+  {
+    constexpr int PIECES = DL_WH * DL_WW * 8;                     // 4480, 17.5 per thread
+#pragma unroll
+    for (int k0 = 0; k0 < 18; k0 += 6) {
+      half8 v[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int i = min(tid + (k0 + k) * 256, PIECES - 1);
+        const int c = i & 7, wpix = i >> 3;
+        const int wy = wpix / DL_WW, wx = wpix - wy * DL_WW;
+        const int iy = min(max(wy0 + wy, 0), p.H - 1), ix = min(max(wx0 + wx, 0), p.W - 1);   // outside the image: never sampled
+        v[k] = *reinterpret_cast<const half8*>(xn + ((long)iy * p.W + ix) * p.x_sp + c * 8);
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int i = min(tid + (k0 + k) * 256, PIECES - 1);
+        const int c = i & 7, wpix = i >> 3;
+        const int wy = wpix / DL_WW, wx = wpix - wy * DL_WW;
+        *reinterpret_cast<half8*>(win + (wy * DL_WP + wx) * 128 + ((c ^ ((wx >> 1) & 7)) << 4)) = v[k];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 3: sample + multiply, no barrier.  Software pipeline of depth one over the 36 k-steps (tap, group pair):
+  // the corner reads and the two A fragments of step i+1 are in flight while step i is combined and multiplied.
+  f32x16 acc[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+  const half_t* wb = p.w + lane * 8;                              // blob [cout tile 2][tap 9][step 4][lane 64][8]
+  DlSample q[2];
+  half8 v[2][4], a[2][2];
+  const char* wbytes = reinterpret_cast<const char*>(p.w);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto issue = [&](auto interior, int i, int sl) {
+    const int t = i >> 2, s2 = i & 3;
+    const int g = 2 * s2 + hh;
+    const half2v o2 = off[s2][t];
+    const float h_im = (float)(oy - 1 + t / 3) + (float)o2[0];
+    const float w_im = (float)(ox - 1 + t % 3) + (float)o2[1];
+    if constexpr (decltype(interior)::value) q[sl] = dl_prepare_interior(wy0, wx0, g, h_im, w_im, msk[s2][t]);
+    else q[sl] = dl_prepare(wy0, wx0, g, p.H, p.W, h_im, w_im, msk[s2][t]);
+    v[sl][0] = *reinterpret_cast<const half8*>(win + q[sl].s00);
+    v[sl][1] = *reinterpret_cast<const half8*>(win + q[sl].s01);
+    v[sl][2] = *reinterpret_cast<const half8*>(win + q[sl].s10);
+    v[sl][3] = *reinterpret_cast<const half8*>(win + q[sl].s11);
+    a[sl][0] = *reinterpret_cast<const half8*>(wbytes + (size_t)(i * 1024) + lane16);
+    a[sl][1] = *reinterpret_cast<const half8*>(wbytes + (size_t)((36 + i) * 1024) + lane16);
+    if (__builtin_amdgcn_ballot_w64(!q[sl].iw) != 0) {            // rare: some lane's sample left the window
+      if (!q[sl].iw) {
+        if constexpr (decltype(interior)::value) q[sl] = dl_prepare(wy0, wx0, g, p.H, p.W, h_im, w_im, msk[s2][t]);   // with the border logic
+        const half_t* xg = xn + g * 8;
+        const int r0 = q[sl].y0 * p.W, r1 = q[sl].y1 * p.W;
+        v[sl][0] = *reinterpret_cast<const half8*>(xg + (long)(r0 + q[sl].x0) * p.x_sp);
+        v[sl][1] = *reinterpret_cast<const half8*>(xg + (long)(r0 + q[sl].x1) * p.x_sp);
+        v[sl][2] = *reinterpret_cast<const half8*>(xg + (long)(r1 + q[sl].x0) * p.x_sp);
+        v[sl][3] = *reinterpret_cast<const half8*>(xg + (long)(r1 + q[sl].x1) * p.x_sp);
+      }
+    }
+  };
+  auto consume = [&](int sl) {
+    half8 b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      b[j] = (half_t)__builtin_fmaf(q[sl].w1, (float)v[sl][0][j],
+                                    __builtin_fmaf(q[sl].w2, (float)v[sl][1][j], __builtin_fmaf(q[sl].w3, (float)v[sl][2][j], q[sl].w4 * (float)v[sl][3][j])));
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[sl][0], b, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[sl][1], b, acc[1], 0, 0, 0);
+  };
+  auto run = [&](auto interior) {
+    issue(interior, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 36; ++i) {
+      if (i + 1 < 36) issue(interior, i + 1, (i + 1) & 1);
+      consume(i & 1);
+    }
+  };
+  // workgroup-uniform: does the window lie inside the image?  (all but the tiles along the image border)
+  if (wy0 >= 0 && wx0 >= 0 && wy0 + DL_WH <= p.H && wx0 + DL_WW <= p.W) run(std::true_type{});
+  else run(std::false_type{});
+
+  if (oy >= p.H || ox >= p.W) return;
+  half_t* yp = reinterpret_cast<half_t*>(p.y.p) + (long)n * p.y.sn + ((long)oy * p.W + ox) * p.y.sp;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int co = mt * 32 + 8 * gq + 4 * hh;
+      if (co >= p.y.C) continue;
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+      half4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = acc[mt][4 * gq + i] + b4[i];
+        if (p.round16) v = (float)(half_t)v;
+        v = act_apply(v, p.act, p.slope);
+        o[i] = (half_t)v;
+      }
+      *reinterpret_cast<half4*>(yp + co) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // fp32 NCHW operator (`_ext.dcn_v2_forward`)
 // block: 64 output pixels; loops over input channels, sampling kh*kw taps of one channel into
 // LDS, then every thread accumulates its (pixel, cout-subset) outputs.
@@ -249,6 +495,10 @@ __global__ __launch_bounds__(256) void dcn_f32_forward_kernel(const DcnF32Params
 
 }  // namespace
 
+static bool g_dcn_lds = getenv("TDVC_DCN_NO_LDS") == nullptr;
+// tests and A/B benchmarks switch the LDS-window kernel off to run the same operator on dcn_fused_kernel
+extern "C" void tdvc_debug_enable_dcn_lds(int enable) { g_dcn_lds = enable != 0; }
+
 extern "C" int tdvc_dcn_fused(const tdvc_dcn_desc* d, void* stream) {
   TDVC_CHECK(d, "tdvc_dcn_fused: null descriptor");
   TDVC_CHECK(fmap_ok16(d->x) && fmap_ok16(d->om) && fmap_ok16(d->y), "tdvc_dcn_fused: fmaps must be fp16, C/sp %% 8, aligned");
@@ -273,6 +523,17 @@ extern "C" int tdvc_dcn_fused(const tdvc_dcn_desc* d, void* stream) {
     const long items = p.npix * G;
     hipLaunchKernelGGL(dcn_planarise_kernel, dim3((unsigned)((items + 255) / 256), d->x.N), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        p.x, p.x_sn, p.x_sp, p.npix, G, reinterpret_cast<half_t*>(d->x_planar));
+  }
+  if (g_dcn_lds && !p.xp && (long)d->x.H * d->x.W >= 8192) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DL_LDS);
+      TDVC_CHECK(err == hipSuccess, "tdvc_dcn_fused: cannot reserve %d bytes of LDS: %s", DL_LDS, hipGetErrorString(err));
+      attr_done = true;
+    }
+    dim3 grid_l((unsigned)(((d->x.W + DL_TX - 1) / DL_TX) * ((d->x.H + DL_TY - 1) / DL_TY)), d->x.N);
+    hipLaunchKernelGGL(dcn_lds_kernel, grid_l, dim3(256), DL_LDS, reinterpret_cast<hipStream_t>(stream), p);
+    return tdvc_launch_status("tdvc_dcn_fused(lds)");
   }
   dim3 grid((unsigned)(((d->x.W + DCN_TPX - 1) / DCN_TPX) * ((d->x.H + DCN_TPY - 1) / DCN_TPY)), d->x.N);
   const size_t lds = (size_t)64 * (DCN_TAPS_PER_CHUNK * G * 16 + 16);

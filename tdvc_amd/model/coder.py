@@ -351,7 +351,10 @@ class Cheng2020Anchor(nn.Module, PackCache):
         for i in range(6, 9):
             t = g[i].run(t)
         # x_hat re-enters an autocast region (pnet.py:51,75): fp16 whatever the coder's precision; the fused `+ res` is
-        # prediction + recon_res of pnet.py:76, summed in fp32 and rounded once
+        # prediction + recon_res of pnet.py:76 fused into the last layer's epilogue.  Maps of < 8192 px (generic epilogue) sum in
+        # fp32 and round once; the 1080p path (conv_mfma_v11, lean epilogue) rounds the conv result to fp16 and adds the
+        # prediction in packed fp16 -- two roundings, <= 1 fp16 ulp of a [0,1] pixel; the 1080p trained-point parity test
+        # (tests/test_model_gpu.py::test_trained_operating_point_parity_1080p) runs through that kernel
         return ops.conv(t, pk_conv(self, "gs9", g[9][0], shuffle=True), out=out, res=res, out_dtype=torch.float16)
 
     def run_h_a(self, y16: FM) -> FM:

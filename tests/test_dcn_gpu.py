@@ -63,7 +63,7 @@ def test_ext_errors():
         _ext.dcn_v2_forward(x, torch.zeros(4, 3, 3, 3).cuda(), b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)
 
 
-@pytest.mark.parametrize("H,W", [(20, 28), (64, 96)])
+@pytest.mark.parametrize("H,W", [(20, 28), (64, 96), (88, 104)])      # the last one is large enough for the LDS-window kernel
 def test_fused_dcn_vs_oracle(H, W, report):
     """fp16 fused kernel (sampling + modulation + contraction + fp16 rounding + LeakyReLU) vs the
     oracle DCN module fed the same fp16-rounded operands"""
@@ -102,6 +102,63 @@ def test_fused_dcn_vs_oracle(H, W, report):
     ops.dcn_fused(to_fm(x, ops), om_fm, pc, a, groups=8, act=ops.ACT_LRELU, slope=0.1, planar=False)
     ops.dcn_fused(to_fm(x, ops), om_fm, pc, b, groups=8, act=ops.ACT_LRELU, slope=0.1, planar=True)
     assert torch.equal(a.t, b.t) and torch.equal(a.t, dst.t), "group-planar gather differs from the NHWC gather"
+
+
+LDS_CASES = [
+    # name, N, H, W, offset sigma (px), coherent shift (dy, dx), poison
+    ("small_offsets", 1, 96, 128, 1.5, (0.0, 0.0), False),
+    ("ragged_tile_edges", 2, 91, 117, 1.5, (0.0, 0.0), False),         # H % 8, W % 16 != 0: overhanging tiles
+    ("coherent_motion", 1, 96, 128, 1.0, (11.3, -7.6), False),         # the window follows the tile's mean displacement
+    ("wild_offsets", 1, 96, 128, 9.0, (0.0, 0.0), False),              # most samples leave the window: fallback gather
+    ("nan_inf_offsets", 1, 96, 128, 1.5, (0.0, 0.0), True),
+]
+
+
+@pytest.mark.parametrize("case", LDS_CASES, ids=[c[0] for c in LDS_CASES])
+def test_dcn_lds_window_kernel_equals_gather_kernel(case, report):
+    """tdvc_dcn_fused takes the LDS-window kernel on maps of >= 8192 pixels; it must reproduce the L1-gather kernel bit for
+    bit whatever the offsets do (same arithmetic, same accumulation order; only the source of the corner vectors differs)"""
+    import ctypes
+
+    from tdvc_amd import _lib, ops
+    name, N, H, W, sigma, shift, poison = case
+    fn = _lib.lib().tdvc_debug_enable_dcn_lds
+    fn.argtypes = [ctypes.c_int]
+    fn.restype = None
+    g = torch.Generator().manual_seed(91)
+    x = torch.randn(N, H, W, 64, generator=g)
+    om = torch.randn(N, H, W, 216, generator=g)
+    om[..., :144] *= sigma
+    om[..., 0:144:2] += shift[0]
+    om[..., 1:144:2] += shift[1]
+    if poison:
+        flat = om.view(-1)
+        idx = torch.randint(0, flat.numel(), (400,), generator=g)
+        flat[idx[:100]] = float("nan")
+        flat[idx[100:200]] = float("inf")
+        flat[idx[200:300]] = -float("inf")
+        flat[idx[300:]] = 60000.0
+    xf, omf = ops.FM(x.half().cuda()), ops.FM(om.half().cuda())
+    pc = ops.pack_conv(torch.randn(64, 64, 3, 3, generator=g) * 0.05, torch.randn(64, generator=g) * 0.1, stride=1, pad=1, ck=64)
+    outs = []
+    try:
+        for on in (1, 0):
+            fn(on)
+            y = ops.FM.empty(N, H, W, 64)
+            ops.dcn_fused(xf, omf, pc, y, groups=8, act=ops.ACT_LRELU, slope=0.1, planar=False)
+            outs.append(y.t.clone())
+    finally:
+        fn(1)
+    a, b = outs
+    if poison:
+        # a NaN/Inf mask poisons its pixel in both kernels alike; compare bit patterns
+        same = torch.equal(a.view(torch.int16), b.view(torch.int16))
+    else:
+        same = torch.equal(a, b)
+        assert bool(torch.isfinite(a).all())
+    nbad = int((a.view(torch.int16) != b.view(torch.int16)).sum())
+    report(f"dcn_lds {name}: {a.numel()} outputs, {nbad} differ from the gather kernel")
+    assert same, f"{nbad} outputs differ"
 
 
 @pytest.mark.parametrize("cfg", [
