@@ -229,7 +229,7 @@ __device__ __forceinline__ DlSample dl_prepare(int wy0, int wx0, int g, int H, i
 __device__ __forceinline__ DlSample dl_prepare_interior(int wy0, int wx0, int g, float h_im, float w_im, float mask) {
   DlSample q;
   const float hf = floorf(h_im), wf = floorf(w_im);
-  q.iw = hf >= (float)wy0 && hf <= (float)(wy0 + DL_WH - 2) && wf >= (float)wx0 && wf <= (float)(wx0 + DL_WW - 2);
+  q.iw = (hf >= (float)wy0) & (hf <= (float)(wy0 + DL_WH - 2)) & (wf >= (float)wx0) & (wf <= (float)(wx0 + DL_WW - 2));
   const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
   q.w1 = hh * hw * mask; q.w2 = hh * lw * mask; q.w3 = lh * hw * mask; q.w4 = lh * lw * mask;
   const int a0 = q.iw ? (int)hf - wy0 : 0, b0 = q.iw ? (int)wf - wx0 : 0, b1 = b0 + 1;
@@ -240,33 +240,38 @@ __device__ __forceinline__ DlSample dl_prepare_interior(int wy0, int wx0, int g,
   return q;
 }
 
+// MODE 0: the operator.  MODE 1 / 2: timing-only builds for tools/ab_dcn.py (1: no sampling / matrix phase, 2: no window
+// staging -- the window holds garbage, control flow and instruction stream unchanged); their output is meaningless.
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void dcn_lds_kernel(const DcnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char win[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid0 = threadIdx.x, lane = tid0 & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int hh = lane >> 5, r = lane & 31;
   const int tiles_x = (p.W + DL_TX - 1) / DL_TX;
   const int tile_id = tdvc_xcd_tile(blockIdx.x);
   const int tx = tile_id % tiles_x, ty = tile_id / tiles_x;
   const int n = blockIdx.y;
   const half_t* xn = p.x + (long)n * p.x_sn;
+  const int tid = tid0;
 
   // ---- phase 1: the tile's offset / mask records -> LDS -> registers
   {
     const half_t* omn = p.om + (long)n * p.om_sn;
     constexpr int PIECES = DL_TY * DL_TX * 27;                    // 3456 16-byte pieces, 13.5 per thread
+    // all 14 loads of a thread are in flight together: staging is a latency chain (2.3 us per round trip at 8 waves per CU)
 #pragma unroll
-    for (int k0 = 0; k0 < 14; k0 += 7) {
-      half8 v[7];
+    for (int k0 = 0; k0 < 14; k0 += 14) {
+      half8 v[14];
 #pragma unroll
-      for (int k = 0; k < 7; ++k) {
+      for (int k = 0; k < 14; ++k) {
         const int i = min(tid + (k0 + k) * 256, PIECES - 1);
         const int pl = i / 27, pc = i - pl * 27;
         const int cy = min(ty * DL_TY + (pl >> 4), p.H - 1), cx = min(tx * DL_TX + (pl & 15), p.W - 1);
         v[k] = *reinterpret_cast<const half8*>(omn + ((long)cy * p.W + cx) * p.om_sp + pc * 8);
       }
 #pragma unroll
-      for (int k = 0; k < 7; ++k) {
+      for (int k = 0; k < 14; ++k) {
         const int i = min(tid + (k0 + k) * 256, PIECES - 1);      // the clamped duplicates rewrite the last piece with itself
         *reinterpret_cast<half8*>(win + i * 16) = v[k];
       }
@@ -310,18 +315,19 @@ __global__ __launch_bounds__(256, 2) void dcn_lds_kernel(const DcnParams p) {
   {
     constexpr int PIECES = DL_WH * DL_WW * 8;                     // 4480, 17.5 per thread
 #pragma unroll
-    for (int k0 = 0; k0 < 18; k0 += 6) {
-      half8 v[6];
+    for (int k0 = 0; k0 < 18; k0 += 18) {
+      half8 v[18];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
+      for (int k = 0; k < 18; ++k) {
         const int i = min(tid + (k0 + k) * 256, PIECES - 1);
         const int c = i & 7, wpix = i >> 3;
         const int wy = wpix / DL_WW, wx = wpix - wy * DL_WW;
         const int iy = min(max(wy0 + wy, 0), p.H - 1), ix = min(max(wx0 + wx, 0), p.W - 1);   // outside the image: never sampled
-        v[k] = *reinterpret_cast<const half8*>(xn + ((long)iy * p.W + ix) * p.x_sp + c * 8);
+        if constexpr (MODE != 2) v[k] = *reinterpret_cast<const half8*>(xn + ((long)iy * p.W + ix) * p.x_sp + c * 8);
+        else v[k] = half8{(half_t)(float)iy, (half_t)(float)ix, 0, 0, 0, 0, 0, 0};
       }
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
+      for (int k = 0; k < 18; ++k) {
         const int i = min(tid + (k0 + k) * 256, PIECES - 1);
         const int c = i & 7, wpix = i >> 3;
         const int wy = wpix / DL_WW, wx = wpix - wy * DL_WW;
@@ -338,11 +344,19 @@ __global__ __launch_bounds__(256, 2) void dcn_lds_kernel(const DcnParams p) {
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
-  const half_t* wb = p.w + lane * 8;                              // blob [cout tile 2][tap 9][step 4][lane 64][8]
   DlSample q[2];
-  half8 v[2][4], a[2][2];
-  const char* wbytes = reinterpret_cast<const char*>(p.w);
-  const unsigned lane16 = (unsigned)lane * 16u;
+  constexpr int APF = 2;                                          // A fragments are fetched (from L2) two steps ahead
+  half8 v[2][4], a[APF + 1][2];
+  // A fragments: blob [cout tile 2][tap 9][step 4][lane 64][8 halves], read through a buffer descriptor (scalar base and
+  // step offset, the lane offset the only vector operand: no 64-bit address arithmetic per load)
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.w), 0, 2 * 36 * 1024, 0x00020000);
+  const int lane16 = lane * 16;
+  float neg0 = -0.f;                                              // x * y == fma(x, y, -0) for every x, y: the opaque addend keeps
+  asm volatile("" : "+v"(neg0));                                  // the first product of the combine on v_fma_mix (fp16 operand)
+  auto issue_a = [&](int i) {
+    a[i % (APF + 1)][0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, i * 1024, 0));
+    a[i % (APF + 1)][1] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, (36 + i) * 1024, 0));
+  };
   auto issue = [&](auto interior, int i, int sl) {
     const int t = i >> 2, s2 = i & 3;
     const int g = 2 * s2 + hh;
@@ -355,8 +369,6 @@ __global__ __launch_bounds__(256, 2) void dcn_lds_kernel(const DcnParams p) {
     v[sl][1] = *reinterpret_cast<const half8*>(win + q[sl].s01);
     v[sl][2] = *reinterpret_cast<const half8*>(win + q[sl].s10);
     v[sl][3] = *reinterpret_cast<const half8*>(win + q[sl].s11);
-    a[sl][0] = *reinterpret_cast<const half8*>(wbytes + (size_t)(i * 1024) + lane16);
-    a[sl][1] = *reinterpret_cast<const half8*>(wbytes + (size_t)((36 + i) * 1024) + lane16);
     if (__builtin_amdgcn_ballot_w64(!q[sl].iw) != 0) {            // rare: some lane's sample left the window
       if (!q[sl].iw) {
         if constexpr (decltype(interior)::value) q[sl] = dl_prepare(wy0, wx0, g, p.H, p.W, h_im, w_im, msk[s2][t]);   // with the border logic
@@ -369,29 +381,35 @@ __global__ __launch_bounds__(256, 2) void dcn_lds_kernel(const DcnParams p) {
       }
     }
   };
-  auto consume = [&](int sl) {
+  auto consume = [&](int i) {
+    const int sl = i & 1;
     half8 b;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       b[j] = (half_t)__builtin_fmaf(q[sl].w1, (float)v[sl][0][j],
-                                    __builtin_fmaf(q[sl].w2, (float)v[sl][1][j], __builtin_fmaf(q[sl].w3, (float)v[sl][2][j], q[sl].w4 * (float)v[sl][3][j])));
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[sl][0], b, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[sl][1], b, acc[1], 0, 0, 0);
+                                    __builtin_fmaf(q[sl].w2, (float)v[sl][1][j],
+                                                   __builtin_fmaf(q[sl].w3, (float)v[sl][2][j], __builtin_fmaf(q[sl].w4, (float)v[sl][3][j], neg0))));
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i % (APF + 1)][0], b, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i % (APF + 1)][1], b, acc[1], 0, 0, 0);
   };
   auto run = [&](auto interior) {
+#pragma unroll
+    for (int i = 0; i < APF; ++i) issue_a(i);
     issue(interior, 0, 0);
 #pragma unroll
     for (int i = 0; i < 36; ++i) {
+      if (i + APF < 36) issue_a(i + APF);
       if (i + 1 < 36) issue(interior, i + 1, (i + 1) & 1);
-      consume(i & 1);
+      consume(i);
     }
   };
-  // workgroup-uniform: does the window lie inside the image?  (all but the tiles along the image border)
-  if (wy0 >= 0 && wx0 >= 0 && wy0 + DL_WH <= p.H && wx0 + DL_WW <= p.W) run(std::true_type{});
-  else run(std::false_type{});
+  if constexpr (MODE != 1) {
+    if (wy0 >= 0 && wx0 >= 0 && wy0 + DL_WH <= p.H && wx0 + DL_WW <= p.W) run(std::true_type{});
+    else run(std::false_type{});
+  }
 
-  if (oy >= p.H || ox >= p.W) return;
-  half_t* yp = reinterpret_cast<half_t*>(p.y.p) + (long)n * p.y.sn + ((long)oy * p.W + ox) * p.y.sp;
+  if (oy < p.H && ox < p.W) {
+    half_t* yp = reinterpret_cast<half_t*>(p.y.p) + (long)n * p.y.sn + ((long)oy * p.W + ox) * p.y.sp;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -409,6 +427,7 @@ __global__ __launch_bounds__(256, 2) void dcn_lds_kernel(const DcnParams p) {
       }
       *reinterpret_cast<half4*>(yp + co) = o;
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -495,9 +514,10 @@ __global__ __launch_bounds__(256) void dcn_f32_forward_kernel(const DcnF32Params
 
 }  // namespace
 
-static bool g_dcn_lds = getenv("TDVC_DCN_NO_LDS") == nullptr;
+static int g_dcn_lds = getenv("TDVC_DCN_NO_LDS") == nullptr ? 1 : 0;
 // tests and A/B benchmarks switch the LDS-window kernel off to run the same operator on dcn_fused_kernel
-extern "C" void tdvc_debug_enable_dcn_lds(int enable) { g_dcn_lds = enable != 0; }
+// (2, 3: the timing-only builds MODE 1, 2 of dcn_lds_kernel)
+extern "C" void tdvc_debug_enable_dcn_lds(int enable) { g_dcn_lds = enable; }
 
 extern "C" int tdvc_dcn_fused(const tdvc_dcn_desc* d, void* stream) {
   TDVC_CHECK(d, "tdvc_dcn_fused: null descriptor");
@@ -527,12 +547,16 @@ extern "C" int tdvc_dcn_fused(const tdvc_dcn_desc* d, void* stream) {
   if (g_dcn_lds && !p.xp && (long)d->x.H * d->x.W >= 8192) {
     static bool attr_done = false;
     if (!attr_done) {
-      const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DL_LDS);
-      TDVC_CHECK(err == hipSuccess, "tdvc_dcn_fused: cannot reserve %d bytes of LDS: %s", DL_LDS, hipGetErrorString(err));
+      for (const void* k : {reinterpret_cast<const void*>(&dcn_lds_kernel<0>), reinterpret_cast<const void*>(&dcn_lds_kernel<1>),
+                            reinterpret_cast<const void*>(&dcn_lds_kernel<2>)}) {
+        const hipError_t err = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, DL_LDS);
+        TDVC_CHECK(err == hipSuccess, "tdvc_dcn_fused: cannot reserve %d bytes of LDS: %s", DL_LDS, hipGetErrorString(err));
+      }
       attr_done = true;
     }
     dim3 grid_l((unsigned)(((d->x.W + DL_TX - 1) / DL_TX) * ((d->x.H + DL_TY - 1) / DL_TY)), d->x.N);
-    hipLaunchKernelGGL(dcn_lds_kernel, grid_l, dim3(256), DL_LDS, reinterpret_cast<hipStream_t>(stream), p);
+    auto kern = g_dcn_lds == 2 ? dcn_lds_kernel<1> : g_dcn_lds == 3 ? dcn_lds_kernel<2> : dcn_lds_kernel<0>;
+    hipLaunchKernelGGL(kern, grid_l, dim3(256), DL_LDS, reinterpret_cast<hipStream_t>(stream), p);
     return tdvc_launch_status("tdvc_dcn_fused(lds)");
   }
   dim3 grid((unsigned)(((d->x.W + DCN_TPX - 1) / DCN_TPX) * ((d->x.H + DCN_TPY - 1) / DCN_TPY)), d->x.N);

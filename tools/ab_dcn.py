@@ -24,8 +24,9 @@ om[..., 0:144:2] += shift[0]
 om[..., 1:144:2] += shift[1]
 om = ops.FM(om.half())
 pc = ops.pack_conv(torch.randn(64, 64, 3, 3) * 0.05, torch.zeros(64), stride=1, pad=1, ck=64)
+mode = int(os.environ.get("TDVC_AB_MODE", "1"))      # 2 / 3: timing-only builds of the LDS kernel (no matrix phase / no window staging)
 res = {}
-for on in (1, 0, 1, 0):
+for on in (mode, 0, mode, 0):
     fn(on)
     y = ops.FM.empty(1, H, W, 64, device="cuda")
     for _ in range(3):
@@ -40,5 +41,5 @@ for on in (1, 0, 1, 0):
     us = e0.elapsed_time(e1) / iters * 1e3
     res.setdefault(on, []).append((us, y.t.clone()))
 fn(1)
-same = torch.equal(res[1][0][1], res[0][0][1])
-print(f"dcn_fused 1080p sigma {sigma} shift {shift}: lds {[round(r[0], 1) for r in res[1]]} us, gather {[round(r[0], 1) for r in res[0]]} us, bit-equal {same}")
+same = torch.equal(res[mode][0][1], res[0][0][1]) if mode else None
+print(f"dcn_fused 1080p sigma {sigma} shift {shift}: lds(mode {mode}) {[round(r[0], 1) for r in res[mode]]} us, gather {[round(r[0], 1) for r in res[0]]} us, bit-equal {same}")
