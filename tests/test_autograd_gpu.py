@@ -444,6 +444,48 @@ def test_full_model_backward_and_steps(report):
     assert logs[-1]["rd_loss"] < logs[0]["rd_loss"]
 
 
+def test_train_steps_reproducible_with_side_stream_at_training_size(report):
+    """Two identical runs of the training recipe (batch 4, 256x256: the size at which the weight gradients on the side stream
+    overlap the SPyNet tail of the sweep for milliseconds) end in bit-identical parameters.  Round 3 found them differing in the
+    second step: device code with packed-FP32 instructions (v_pk_add_f32) returned wrong values in lanes 48..63 of some waves
+    while the other stream ran MFMA kernels (tools/race_warp_bwd.py); the library is built without those instructions."""
+    from tdvc_amd import ops
+    from tdvc_amd.model import VideoCompressor
+    from tdvc_amd.synth import fill_parameters, make_gop, ref_list
+    from tdvc_amd.train import TrainStep
+    gops = [make_gop(5000 + k, 7, 256, 256) for k in range(2)]
+    batches = []
+    for t0 in (1, 3):
+        xs, rs = [], []
+        for g in gops:
+            for t in (t0, t0 + 1):
+                prev = [g[k:k + 1] for k in range(0, t)]
+                xs.append(g[t:t + 1])
+                rs.append(ref_list(prev[-4:] if t > 3 else prev))
+        batches.append((torch.cat(xs).cuda(), torch.cat(rs).cuda()))
+
+    def run():
+        torch.manual_seed(1111)
+        ops.DETERMINISTIC = True
+        try:
+            net = VideoCompressor()
+            fill_parameters(net)
+            net = net.cuda().train()
+            step = TrainStep(net, train_lambda=256.0, lr=2e-4, loss_scale=128.0)          # side stream + mirror pool: the defaults
+            logs = [step(x, r) for x, r in batches for _ in range(2)]
+            torch.cuda.synchronize()
+        finally:
+            ops.DETERMINISTIC = False
+        return {k: v.detach().clone() for k, v in net.state_dict().items()}, logs
+
+    sa, la = run()
+    sb, lb = run()
+    bad = [k for k in sa if not torch.equal(sa[k], sb[k])]
+    report(f"4 training steps at 4x256x256, twice: {len(bad)}/{len(sa)} state tensors differ; rd_loss {[round(l['rd_loss'], 4) for l in la]}")
+    assert not bad, f"training is not reproducible run to run: {len(bad)} tensors differ, e.g. {bad[:4]}"
+    assert [l["rd_loss"] for l in la] == [l["rd_loss"] for l in lb]
+
+
 def test_train_step_graph_replay_matches_eager(report):
     """TrainStep(graph=True) replays the captured forward + backward: same trajectory as the eager step on the same sample
     (the noise draws differ, so to a tolerance), the gradient buckets re-zeroed inside the graph, MSE reduced outside it"""

@@ -206,3 +206,44 @@ def test_resize_bilinear_backward(src, dst, report):
     # accumulation: a second call adds
     ops.resize_bilinear_backward(to_fm(g, ops, 2, torch.float32), dx, sc.cuda())
     assert_close(fm_to_cpu(dx), 2 * x.grad, 2e-5, 2e-5, "resize_bilinear backward accumulates", report)
+
+
+def test_spynet_backward_tail_reproducible_under_concurrent_stream(report):
+    """zero mirror -> accumulate -> spynet_level_input_backward, repeated while a second stream runs 7x7 weight-gradient
+    launches: every repetition must equal the unloaded result bit for bit (the reproducer of the packed-FP32 finding of round
+    3: with v_pk_add_f32 in the kernel 28-30 of 30 loaded runs differed, always in lanes 48..63 of a wave)"""
+    from tdvc_amd import ops
+    N, H, W = 4, 256, 256
+    g = torch.Generator(device="cuda").manual_seed(5)
+    supp = ops.FM(torch.rand(N, H, W, 4, device="cuda", generator=g))
+    flow_up = ops.FM(torch.randn(N, H, W, 2, device="cuda", generator=g) * 2.0)
+    dcat8 = ops.FM((torch.randn(N, H, W, 8, device="cuda", generator=g) * 1e-3).half())
+    dflow = ops.FM(torch.randn(N, H, W, 2, device="cuda", generator=g) * 1e-3)
+    x = ops.FM(torch.randn(N, H, W, 32, device="cuda", generator=g).half())
+    gy = ops.FM(torch.randn(N, H, W, 64, device="cuda", generator=g).half())
+    pc = ops.pack_conv(torch.randn(64, 32, 7, 7) * 0.02, torch.zeros(64), stride=1, pad=3)
+    dw, db = torch.zeros(64 * 32 * 49, device="cuda"), torch.zeros(64, device="cuda")
+    side = torch.cuda.Stream()
+
+    def tail():
+        dup = ops.FM(torch.zeros_like(flow_up.t))
+        dlo = ops.FM(torch.zeros(N, H // 2, W // 2, 2, device="cuda"))
+        ops.scale_act_res(dup, dup, res=dflow, res_sign=1.0)
+        ops.spynet_level_input_backward(supp, flow_up, dcat8, dup, dlo)
+        return dup.t, dlo.t
+
+    ref = [t.clone() for t in tail()]
+    torch.cuda.synchronize()
+    bad = 0
+    for _ in range(12):
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            for _ in range(3):
+                ops.conv_wgrad(pc, gy, x, dw, scale=1.0, db=db)
+        out = tail()
+        torch.cuda.synchronize()
+        bad += not (torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]))
+    report(f"SPyNet level backward tail under a concurrent weight-gradient stream: {bad}/12 runs differ from the unloaded result")
+    assert bad == 0
