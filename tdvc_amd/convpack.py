@@ -131,6 +131,12 @@ def dgrad_tables(lay: WeightLayout, *, g_channels: int, x_channels: int, taps, p
         assert kh - 1 - pad >= 0 and kh == kw
         mtaps = [(kh - 1 - dy, kw - 1 - dx) for dy, dx in taps]
         tap_off = np.array([lay.tap_src[dy * kw + dx] for dy, dx in taps], dtype=np.int64)
+        # mirrored taps in raster order: the dense-window kernels (conv_mfma_v10 / v11 / n16: tap t = (t / kw, t % kw)) then take the
+        # data gradients too (round 3: with the mirrored list they fell back to conv_mfma_v3, 122 launches of a training step at
+        # 0.16 of the MFMA peak)
+        order = sorted(range(len(mtaps)), key=lambda i: mtaps[i])
+        mtaps = [mtaps[i] for i in order]
+        tap_off = tap_off[order]
         return _tables(device, x_channels, g_channels, kh, kw, kh - 1 - pad, mtaps, ck, False, xrow, gchan, tap_off)
     assert stride == 2 and kh == kw and kh in (1, 3) and len(taps) == kh * kw
     s_kh = int(lay.tap_src[kw] - lay.tap_src[0]) if kh > 1 else 0
