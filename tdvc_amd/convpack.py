@@ -16,6 +16,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass, field
 
+import os
+
 import numpy as np
 import torch
 
@@ -132,8 +134,8 @@ def dgrad_tables(lay: WeightLayout, *, g_channels: int, x_channels: int, taps, p
         mtaps = [(kh - 1 - dy, kw - 1 - dx) for dy, dx in taps]
         tap_off = np.array([lay.tap_src[dy * kw + dx] for dy, dx in taps], dtype=np.int64)
         # mirrored taps in raster order: the dense-window kernels (conv_mfma_v10 / v11 / n16: tap t = (t / kw, t % kw)) then take the
-        # data gradients too (round 3: with the mirrored list they fell back to conv_mfma_v3, 122 launches of a training step at
-        # 0.16 of the MFMA peak)
+        # data gradients too (round 3: with the mirrored list they fell back to conv_mfma_v3, 122 launches of a training step; the
+        # step time itself did not move measurably: 31-45 ms from process to process, the side stream's weight gradients bound it)
         order = sorted(range(len(mtaps)), key=lambda i: mtaps[i])
         mtaps = [mtaps[i] for i in order]
         tap_off = tap_off[order]

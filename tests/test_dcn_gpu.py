@@ -104,6 +104,42 @@ def test_fused_dcn_vs_oracle(H, W, report):
     assert torch.equal(a.t, b.t) and torch.equal(a.t, dst.t), "group-planar gather differs from the NHWC gather"
 
 
+def test_fractional_offsets_closed_form_on_affine_image(report):
+    """the HIP operators against a closed form that needs no oracle (tests/test_oracle_dcn.py::affine_dcn_case: bilinear
+    sampling is exact on an affine image): the fp32 `_ext` operator, and the fused fp16 kernels (gather and LDS-window) at the
+    hot-path geometry with fp16-rounded operands"""
+    import _ext
+    from test_oracle_dcn import affine_dcn_case
+    from tdvc_amd import ops
+    x, w, b, off, m, want, ok = affine_dcn_case()
+    got = _ext.dcn_v2_forward(x.cuda(), w.cuda(), b.cuda(), off.cuda(), m.cuda(), 3, 3, 1, 1, 1, 1, 1, 1, 2).cpu().double()
+    sel = ok.unsqueeze(1).expand_as(want)
+    e32 = float((got - want)[sel].abs().max())
+    report(f"_ext.dcn_v2_forward vs the closed form on an affine image ({int(ok.sum())} interior pixels): max |d| {e32:.3e}")
+    assert e32 < 2e-4 * max(1.0, float(want[sel].abs().max()))
+    # fused fp16 kernels: 8 groups x 8 channels, 64 outputs; 96 x 128 pixels take the LDS-window kernel, 40 x 48 the gather kernel
+    for H, W in ((96, 128), (40, 48)):
+        x, w, b, off, m, _, ok = affine_dcn_case(N=1, G=8, cpg=8, Cout=64, H=H, W=W, seed=11, osc=1.4)
+        x = (x * (4.0 / float(x.abs().max()))).half().float()               # fp16-exact operands, |x| <= 4
+        w, off = w.half().float(), off.half().float()
+        logit = torch.logit(m.clamp(1e-4, 1 - 1e-4)).half().float()            # the fused kernel takes mask LOGITS
+        m = torch.sigmoid(logit)
+        from oracle.tdvc_ref.blocks import dcn_v2_forward_ref
+        # closed form re-evaluated on the rounded operands: x is no longer exactly affine after fp16 rounding, so the reference
+        # for the fp16 kernels is the restatement (itself pinned by the closed form above and in tests/test_oracle_dcn.py)
+        want16 = dcn_v2_forward_ref(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 8)
+        om = torch.cat((off, logit), 1).permute(0, 2, 3, 1).contiguous()         # NHWC [offsets 144 | mask logits 72]
+        pc = ops.pack_conv(w, b, stride=1, pad=1, ck=64)
+        y = ops.FM.empty(1, H, W, 64)
+        ops.dcn_fused(ops.FM(x.permute(0, 2, 3, 1).contiguous().half().cuda()), ops.FM(om.half().cuda()), pc, y, groups=8, round16=True, planar=False)
+        gotf = y.t.float().cpu().permute(0, 3, 1, 2)
+        sel = ok.unsqueeze(1).expand_as(gotf)
+        d = (gotf - want16)[sel].abs()
+        tol = 4e-3 * (1.0 + want16[sel].abs())
+        report(f"fused DCN {H}x{W} on the (fp16-rounded) affine image, interior pixels: max |d| {float(d.max()):.3e} (|out| <= {float(want16[sel].abs().max()):.2f})")
+        assert bool((d <= tol).all())
+
+
 LDS_CASES = [
     # name, N, H, W, offset sigma (px), coherent shift (dy, dx), poison
     ("small_offsets", 1, 96, 128, 1.5, (0.0, 0.0), False),

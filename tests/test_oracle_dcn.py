@@ -45,3 +45,46 @@ def test_gradcheck_reference_settings():
     b = torch.rand(outC, generator=g).double().requires_grad_()
     assert torch.autograd.gradcheck(dcn_c.DCNv2Function.apply, (x, off, msk, w, b, 1, 1, 1, 1),
                                     eps=1e-3, atol=1e-4, rtol=1e-2, nondet_tol=1e-6)
+
+
+def affine_dcn_case(N=1, G=2, cpg=3, Cout=5, H=14, W=17, k=3, seed=7, osc=1.2):
+    """A case whose answer is known in closed form, FRACTIONAL offsets included: on an image that is affine in (h, w) per channel,
+    x[c,h,w] = A_c h + B_c w + C_c, bilinear interpolation is exact, so the sample of channel c at tap (i, j) of pixel (h, w)
+    is A_c (h - 1 + i + dh) + B_c (w - 1 + j + dw) + C_c wherever the four corners lie inside the image, and
+    out[co] = bias[co] + sum_{c,t} W[co,c,t] m[g(c),t] sample(c,t)   (dcn_v2_im2col_cuda.cu:125-195, dcn_v2_cuda.cu:69-92).
+    Returns the operands, the closed-form output and the mask of pixels all of whose samples are interior."""
+    g = torch.Generator().manual_seed(seed)
+    C, K = G * cpg, k * k
+    A, B, C0 = torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g)
+    hh = torch.arange(H, dtype=torch.float64).view(1, 1, H, 1)
+    ww = torch.arange(W, dtype=torch.float64).view(1, 1, 1, W)
+    x = (A.double().view(1, C, 1, 1) * hh + B.double().view(1, C, 1, 1) * ww + C0.double().view(1, C, 1, 1)).expand(N, C, H, W).contiguous()
+    w = torch.randn(Cout, C, k, k, generator=g) * 0.2
+    b = torch.randn(Cout, generator=g)
+    off = (torch.rand(N, 2 * G * K, H, W, generator=g) * 2 - 1) * osc            # fractional, |.| <= osc
+    m = torch.sigmoid(torch.randn(N, G * K, H, W, generator=g))
+    out = b.double().view(1, Cout, 1, 1).expand(N, Cout, H, W).clone()
+    ok = torch.ones(N, H, W, dtype=torch.bool)
+    for gi in range(G):
+        for t in range(K):
+            i, j = t // k, t % k
+            ph = hh.view(1, H, 1) - 1 + i + off[:, gi * 2 * K + 2 * t].double()     # (N, H, W)
+            pw = ww.view(1, 1, W) - 1 + j + off[:, gi * 2 * K + 2 * t + 1].double()
+            ok &= (ph >= 0) & (ph <= H - 1) & (pw >= 0) & (pw <= W - 1)
+            for cc in range(cpg):
+                c = gi * cpg + cc
+                samp = (A[c].double() * ph + B[c].double() * pw + C0[c].double()) * m[:, gi * K + t].double()
+                out += w[:, c, i, j].double().view(1, Cout, 1, 1) * samp.unsqueeze(1)
+    return x.float(), w, b, off, m, out, ok
+
+
+def test_fractional_offsets_closed_form_on_affine_image():
+    """Pins the FRACTIONAL-offset sampling (the zero-offset KAT and the integer-shift property do not): the C restatement and the
+    torch restatement against the closed form on an affine image"""
+    x, w, b, off, m, want, ok = affine_dcn_case()
+    assert int(ok.sum()) > 40                                  # enough interior pixels
+    sel = ok.unsqueeze(1).expand_as(want)
+    for name, fn in (("C restatement", dcn_c.forward), ("torch restatement", dcn_v2_forward_ref)):
+        got = fn(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 2).double()
+        err = float((got - want)[sel].abs().max())
+        assert err < 2e-4 * max(1.0, float(want[sel].abs().max())), f"{name}: max |out - closed form| = {err:.3e}"
