@@ -65,6 +65,9 @@ static int g_v11_experiment = 0;     // diagnostic builds only (wrong results): 
 // a piece costs its issuing wave 100-185 cycles).  Letting waves 4-7 issue their pieces in the MIDDLE of the group (after 6 of
 // its 12 MFMAs) was 2-3 % SLOWER on four layer shapes (162.3 against 158.3 us at 128 -> 128 @544x960): the asm statement in
 // the middle of the group splits the scheduling region and the pinned read / MFMA interleave degenerates into read pairs.
+// Measured and dropped (round 3, tools/bench_v11_res.py, two builds back to back on one box): the residual rows of the epilogue
+// requested two output rows ahead of their use (a ring of two rows; all four at once spill 13 registers that are then reloaded
+// inside the matrix phase): 167.5 / 167.9 against 172.7 / 167.5 us at 128 -> 128 @544x960 with one residual -- no difference.
 template <bool STAMP = false>
 __global__ __launch_bounds__(NTHR11, 1) void conv_mfma_v11_kernel(const ConvParams p, const V11Extra e, long long* stamps = nullptr, int stamp_cap = 0) {
   long long stv[16];
