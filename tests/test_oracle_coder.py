@@ -125,3 +125,52 @@ def test_lower_bound_backward_rule():
     assert float(lik2) == pytest.approx(1e-9)
     (-torch.log2(lik2)).sum().backward()
     assert float(y2.grad) >= 0.0 and float(sc2.grad) <= 0.0      # (the tail pdf underflows in fp32: the sign is what is pinned)
+
+
+def test_gaussian_conditional_is_the_discretised_normal():
+    """An independent pin of the Gaussian rate term (no compressai here, no vectors in the reference): the likelihood of a
+    quantised value q = round(y - mu) under N(mu, s^2) is the mass of [q - 1/2, q + 1/2], computed here in float64 with
+    math.erf; s is bounded below by 0.11 and the likelihood by 1e-9 (compressai's GaussianConditional defaults)."""
+    import math
+    g = torch.Generator().manual_seed(3)
+    gc = oc.GaussianConditional()
+    y = torch.randn(4000, generator=g) * 6.0
+    mu = torch.randn(4000, generator=g) * 2.0
+    s = torch.rand(4000, generator=g) * 4.0 + 0.01                     # some below the 0.11 bound
+    out, lik = gc(y.view(1, 1, 1, -1), s.view(1, 1, 1, -1), mu.view(1, 1, 1, -1), training=False)
+    out, lik = out.flatten(), lik.flatten()
+    Phi = lambda t: 0.5 * (1.0 + math.erf(t / math.sqrt(2.0)))
+    worst = 0.0
+    for i in range(0, 4000, 7):
+        q = round(float(y[i]) - float(mu[i]))                             # Python rounds half to even, like torch.round
+        assert float(out[i]) == pytest.approx(q + float(mu[i]), abs=1e-5)
+        sd = max(float(s[i]), 0.11)
+        want = max(Phi((q + 0.5) / sd) - Phi((q - 0.5) / sd), 1e-9)
+        worst = max(worst, abs(float(lik[i]) - want) / want if want > 1e-6 else abs(float(lik[i]) - want))
+    assert worst < 2e-3, worst                                            # fp32 erfc differences in the far tail
+    # and it is a distribution: the masses of all integers sum to one
+    ks = torch.arange(-400, 401, dtype=torch.float32)
+    for sd in (0.11, 0.7, 3.0, 40.0):
+        tot = float(gc.likelihood(ks, torch.full_like(ks, sd)).double().sum())
+        assert abs(tot - 1.0) < 1e-5, (sd, tot)
+
+
+def test_factorized_prior_is_a_distribution():
+    """EntropyBottleneck: per channel the cumulative logits are increasing and the likelihoods of all integers sum to one
+    (whatever the parameters: the construction guarantees it; a transcription error in the matrix / bias / factor chain does
+    not survive this)"""
+    torch.manual_seed(5)
+    eb = oc.EntropyBottleneck(6)
+    with torch.no_grad():
+        for n, p_ in eb.named_parameters():
+            if "quantiles" not in n:
+                p_.add_(torch.randn_like(p_) * 0.3)                       # away from the initialisation
+    x = torch.linspace(-60, 60, 2401).view(1, 1, -1).expand(6, 1, -1)
+    with torch.no_grad():
+        lc = eb.logits_cumulative(x)
+        assert bool((lc[..., 1:] >= lc[..., :-1]).all())
+        ks = torch.arange(-300, 301, dtype=torch.float32).view(1, 1, -1).expand(6, 1, -1)
+        lik = eb.likelihood(ks).double()
+    assert bool((lik >= 0).all())
+    tot = lik.sum(dim=-1).flatten()
+    assert float((tot - 1.0).abs().max()) < 1e-4, tot.tolist()
