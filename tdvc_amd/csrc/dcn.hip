@@ -256,26 +256,27 @@ __global__ __launch_bounds__(256, 2) void dcn_lds_kernel(const DcnParams p) {
   const int tid = tid0;
 
   // ---- phase 1: the tile's offset / mask records -> LDS -> registers
+  // Staging indices are chosen so that everything that varies from piece to piece is wave-uniform (scalar ALU, immediate LDS
+  // offsets): thread = (piece slot tid & 31 of the 27-piece record, pixel tid >> 5 of a group of 8); 16 groups of 8 pixels =
+  // the tile, group k = row k >> 1, columns 8 (k & 1) .. + 7.  (The first version divided a flat piece index by 27 and by 28:
+  // ~740 of the kernel's ~4 300 vector instructions per wave and tile.  Removing them moved the kernel from 724 to 716 us: it
+  // is not bound by the instruction count.)  All 16 loads of a thread are in flight together.
   {
     const half_t* omn = p.om + (long)n * p.om_sn;
-    constexpr int PIECES = DL_TY * DL_TX * 27;                    // 3456 16-byte pieces, 13.5 per thread
-    // all 14 loads of a thread are in flight together: staging is a latency chain (2.3 us per round trip at 8 waves per CU)
+    const int ps = tid & 31, pj = tid >> 5;
+    const bool pv = ps < 27;
+    const int pcl = pv ? ps : 26;
+    half8 v[16];
 #pragma unroll
-    for (int k0 = 0; k0 < 14; k0 += 14) {
-      half8 v[14];
-#pragma unroll
-      for (int k = 0; k < 14; ++k) {
-        const int i = min(tid + (k0 + k) * 256, PIECES - 1);
-        const int pl = i / 27, pc = i - pl * 27;
-        const int cy = min(ty * DL_TY + (pl >> 4), p.H - 1), cx = min(tx * DL_TX + (pl & 15), p.W - 1);
-        v[k] = *reinterpret_cast<const half8*>(omn + ((long)cy * p.W + cx) * p.om_sp + pc * 8);
-      }
-#pragma unroll
-      for (int k = 0; k < 14; ++k) {
-        const int i = min(tid + (k0 + k) * 256, PIECES - 1);      // the clamped duplicates rewrite the last piece with itself
-        *reinterpret_cast<half8*>(win + i * 16) = v[k];
-      }
+    for (int k = 0; k < 16; ++k) {
+      const int cy = min(ty * DL_TY + (k >> 1), p.H - 1);                      // uniform
+      const int cx = min(tx * DL_TX + 8 * (k & 1) + pj, p.W - 1);
+      v[k] = *reinterpret_cast<const half8*>(omn + (long)cy * p.W * p.om_sp + (cx * p.om_sp + pcl * 8));
     }
+    unsigned char* dst = win + pj * DL_OM_REC + pcl * 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (pv) *reinterpret_cast<half8*>(dst + k * 8 * DL_OM_REC) = v[k];
   }
   __syncthreads();
   const int pl = (2 * wave + (r >> 4)) * DL_TX + (r & 15);
@@ -313,27 +314,22 @@ __global__ __launch_bounds__(256, 2) void dcn_lds_kernel(const DcnParams p) {
   // ---- phase 2: the window of x -> LDS (swizzled)
   const int wy0 = ty * DL_TY - DL_M + cy, wx0 = tx * DL_TX - DL_M + cx;
   {
-    constexpr int PIECES = DL_WH * DL_WW * 8;                     // 4480, 17.5 per thread
+    // thread = (channel chunk tid & 7, column slot tid >> 3 of 32, 28 used); one window row per load, the row a scalar
+    const int c = tid & 7, wx = tid >> 3;
+    const bool wv = wx < DL_WW;
+    const int ix = min(max(wx0 + (wv ? wx : 0), 0), p.W - 1);                  // outside the image: never sampled
+    const int lane_off = ix * p.x_sp + c * 8;
+    half8 v[DL_WH];
 #pragma unroll
-    for (int k0 = 0; k0 < 18; k0 += 18) {
-      half8 v[18];
-#pragma unroll
-      for (int k = 0; k < 18; ++k) {
-        const int i = min(tid + (k0 + k) * 256, PIECES - 1);
-        const int c = i & 7, wpix = i >> 3;
-        const int wy = wpix / DL_WW, wx = wpix - wy * DL_WW;
-        const int iy = min(max(wy0 + wy, 0), p.H - 1), ix = min(max(wx0 + wx, 0), p.W - 1);   // outside the image: never sampled
-        if constexpr (MODE != 2) v[k] = *reinterpret_cast<const half8*>(xn + ((long)iy * p.W + ix) * p.x_sp + c * 8);
-        else v[k] = half8{(half_t)(float)iy, (half_t)(float)ix, 0, 0, 0, 0, 0, 0};
-      }
-#pragma unroll
-      for (int k = 0; k < 18; ++k) {
-        const int i = min(tid + (k0 + k) * 256, PIECES - 1);
-        const int c = i & 7, wpix = i >> 3;
-        const int wy = wpix / DL_WW, wx = wpix - wy * DL_WW;
-        *reinterpret_cast<half8*>(win + (wy * DL_WP + wx) * 128 + ((c ^ ((wx >> 1) & 7)) << 4)) = v[k];
-      }
+    for (int wy = 0; wy < DL_WH; ++wy) {
+      const int iy = min(max(wy0 + wy, 0), p.H - 1);                           // uniform
+      if constexpr (MODE != 2) v[wy] = *reinterpret_cast<const half8*>(xn + (long)iy * p.W * p.x_sp + lane_off);
+      else v[wy] = half8{(half_t)(float)iy, (half_t)(float)ix, 0, 0, 0, 0, 0, 0};
     }
+    unsigned char* dst = win + (wv ? wx : 0) * 128 + ((c ^ ((wx >> 1) & 7)) << 4);
+#pragma unroll
+    for (int wy = 0; wy < DL_WH; ++wy)
+      if (wv) *reinterpret_cast<half8*>(dst + wy * DL_WP * 128) = v[wy];
   }
   __syncthreads();
 

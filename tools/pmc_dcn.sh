@@ -10,7 +10,7 @@ for c in "$@"; do
   f=$(find "$out" -name "*counter_collection.csv" | head -1)
   python3 - "$f" "$c" <<'PY'
 import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "dcn_fused" in r["Kernel_Name"] and r["Counter_Name"] == sys.argv[2]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "dcn_" in r["Kernel_Name"] and r["Counter_Name"] == sys.argv[2]]
 v = [float(r["Counter_Value"]) for r in rows]
 print(sys.argv[2], sum(v) / max(len(v), 1), "launches", len(v))
 PY
