@@ -28,6 +28,9 @@ gy = ops.FM(torch.randn(N, H, W, 64, device="cuda", generator=g).half())
 pc = ops.pack_conv(torch.randn(64, 32, 7, 7) * 0.02, torch.zeros(64), stride=1, pad=3)
 dw, db = torch.zeros(64 * 32 * 49, device="cuda"), torch.zeros(64, device="cuda")
 side = torch.cuda.Stream()
+LOAD = os.environ.get("PK_LOAD", "wgrad")
+big1 = torch.randn(64 << 20, device="cuda", generator=g)
+big2 = torch.empty_like(big1)
 
 
 def run(v):
@@ -37,7 +40,8 @@ def run(v):
     return c
 
 
-for v in (4, 7, 8, 9, 10, 11, 12, 8):
+print(f"side-stream load: {LOAD}")
+for v in ((10, 11) if LOAD != "wgrad" else (0, 4, 7, 9, 10, 11, 12, 8)):
     ref = run(v)
     torch.cuda.synchronize()
     bad, lanes = 0, torch.zeros(64, dtype=torch.long, device="cuda")
@@ -46,8 +50,15 @@ for v in (4, 7, 8, 9, 10, 11, 12, 8):
         ev.record()
         with torch.cuda.stream(side):
             side.wait_event(ev)
-            for _ in range(3):
-                ops.conv_wgrad(pc, gy, x, dw, scale=1.0, db=db)
+            if LOAD == "wgrad":                            # MFMA kernels
+                for _ in range(3):
+                    ops.conv_wgrad(pc, gy, x, dw, scale=1.0, db=db)
+            elif LOAD == "copy":                           # memory-bound, no matrix instructions
+                for _ in range(6):
+                    big2.copy_(big1)
+            elif LOAD == "valu":                           # vector-ALU bound, no matrix instructions
+                for _ in range(3):
+                    torch.erfinv(torch.tanh(big1), out=big2)
         c = run(v)
         torch.cuda.synchronize()
         d = (c != ref).any(dim=1)
