@@ -183,17 +183,22 @@ def measure_pair_traffic():
         f"(FETCH_SIZE {vals['FETCH_SIZE']:.0f} KB x 2 [gfx950 wide-read correction] + WRITE_SIZE {vals['WRITE_SIZE']:.0f} KB)")
 
 
-def _time_launches(fn, reps=20):
-    """average duration of `reps` back-to-back launches of fn() on torch's current stream (= the launch stream)"""
+def _time_launches(fn, reps=20, loops=3):
+    """average duration of `reps` back-to-back launches of fn() on torch's current stream (= the launch stream): the median of
+    `loops` such loops (like the conv representatives: the first loop after an idle period runs 10-12 % slower, the clock is
+    still ramping)"""
     fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    ms = []
+    for _ in range(loops):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1) / reps)
+    return sorted(ms)[len(ms) // 2]
 
 
 def hbm_rooflines(model):
