@@ -144,3 +144,28 @@ def test_product_has_no_cpu_fallback():
     with pytest.raises(RuntimeError):
         _ext.dcn_v2_forward(torch.zeros(1, 2, 4, 4), torch.zeros(2, 2, 3, 3), torch.zeros(2), torch.zeros(1, 18, 4, 4),
                             torch.zeros(1, 9, 4, 4), 3, 3, 1, 1, 1, 1, 1, 1, 1)
+
+
+def test_no_packed_fp32_instructions_in_the_device_code(tmp_path):
+    """The library must not contain v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: on MI355X a packed-FP32 instruction with an
+    operand swizzle returned wrong values in lanes 48..63 while another stream ran MFMA kernels (tools/race_pk_min.py,
+    DESIGN.md section 4).  The Makefile switches the instruction class off; this guards the switch."""
+    import re
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump of the ROCm toolchain not found")
+    lib = tmp_path / "libtdvc_hip.so"
+    shutil.copy(L.LIB_PATH, lib)
+    subprocess.run([objdump, "--offloading", str(lib)], check=True, capture_output=True, cwd=tmp_path)      # extracts the code objects
+    objs = sorted(tmp_path.glob("libtdvc_hip.so.*gfx950*"))
+    assert objs, "no gfx950 code object found in the library"
+    pat = re.compile(r"\bv_pk_(add|mul|fma)_f32\b")
+    hits, mfma = 0, 0
+    for o in objs:
+        text = subprocess.run([objdump, "-d", str(o)], check=True, capture_output=True, text=True).stdout
+        hits += len(pat.findall(text))
+        mfma += text.count("v_mfma_f32_32x32x16")
+    assert mfma > 1000, "the disassembly does not look like the library's device code"
+    assert hits == 0, f"{hits} packed-FP32 instructions in the device code: build with csrc/Makefile's NOPK flag"
