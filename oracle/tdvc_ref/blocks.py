@@ -10,12 +10,71 @@ importing the reference's own `main/model/{pnet,flownet,inflate}.py` and
 `main/utils/utils.py` in the build container (tests/golden/make_golden.py), and for the
 deformable conv against the reference's `check_zero_offset` known-answer test and
 `gradcheck` settings (`main/utils/dcnv2/testcpu.py:34-99`).
+
+AMP emulation (`amp_region`, switched on by `codec.VideoCompressor.amp_emulation`): what the
+reference computes on a GPU with `enable_amp: True` (`cfg/predict.yaml:7`) inside its three
+`torch.cuda.amp.autocast` regions (`main/model/pnet.py:27-31,51-55,75-78`), restated with REAL
+fp16 CPU tensors so that torch's own type promotion decides every intermediate dtype as it does
+on the GPU: convolutions cast input, weight and bias to fp16, accumulate in fp32 and store fp16
+(autocast's fp16 list); element-wise ops, pooling, bilinear resizing, cat run in the dtype(s)
+they are given; `grid_sample`, `norm` (inside `F.normalize`) and `cosine_similarity` run in fp32
+(autocast's fp32 list).  The deformable conv keeps its explicit `.float()` operands and fp32
+weight (`dcn_v2_amp.py:37-42`).  One deliberate deviation: the patch-matching similarity
+(`pnet.py:230-236`) stays an fp32 product of the (fp16-valued) pooled features instead of an fp16
+`bmm` -- its argmax is discrete, and the rounding of a cuBLAS result is not a function this file
+could pin.  Off (the default): every class below is the plain fp32 CPU path, bit for bit what the
+golden vectors pin.
 """
 from __future__ import annotations
+
+import contextlib
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------
+# AMP emulation (see the module docstring)
+# --------------------------------------------------------------------------------------
+class _Amp:
+    on = False          # True while inside an emulated `autocast(enabled=True)` region
+
+
+@contextlib.contextmanager
+def amp_region(enabled: bool):
+    prev = _Amp.on
+    _Amp.on = bool(enabled)
+    try:
+        yield
+    finally:
+        _Amp.on = prev
+
+
+def _h(t):
+    return None if t is None else t.to(torch.float16).float()
+
+
+def _f32(t):
+    """autocast's fp32 cast policy (grid_sampler, norm, cosine_similarity)"""
+    return t.float() if _Amp.on else t
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d whose forward follows autocast's fp16 policy inside an `amp_region`: operands rounded to fp16, fp32
+    accumulation, fp16 result.  State-dict keys and the fp32 path are nn.Conv2d's."""
+
+    def forward(self, x):
+        if not _Amp.on:
+            return super().forward(x)
+        return F.conv2d(_h(x), _h(self.weight), _h(self.bias), self.stride, self.padding, self.dilation, self.groups).half()
+
+
+class Conv3d(nn.Conv3d):
+    def forward(self, x):
+        if not _Amp.on:
+            return super().forward(x)
+        return F.conv3d(_h(x), _h(self.weight), _h(self.bias), self.stride, self.padding, self.dilation, self.groups).half()
 
 
 # --------------------------------------------------------------------------------------
@@ -28,7 +87,7 @@ class ConvAct(nn.Module):
 
     def __init__(self, cin, cout, k, stride=1, padding=0, act=None):
         super().__init__()
-        self.conv = nn.Conv2d(cin, cout, k, stride, padding, bias=True)
+        self.conv = Conv2d(cin, cout, k, stride, padding, bias=True)
         if act == "relu":
             self.activate = nn.ReLU()
         elif act == "sigmoid":
@@ -62,8 +121,8 @@ class Res_Block(nn.Module):
 
     def __init__(self, channels=64):
         super().__init__()
-        self.conv1 = nn.Conv2d(channels, channels, 3, 1, 1)
-        self.conv2 = nn.Conv2d(channels, channels, 3, 1, 1)
+        self.conv1 = Conv2d(channels, channels, 3, 1, 1)
+        self.conv2 = Conv2d(channels, channels, 3, 1, 1)
 
     def forward(self, x):
         return x + self.conv2(F.relu(self.conv1(x)))
@@ -110,7 +169,7 @@ def flow_warp_border(x, flow_nhw2):
     gy = gy.to(x) + flow_nhw2[..., 1]
     nx = 2.0 * gx / max(w - 1, 1) - 1.0
     ny = 2.0 * gy / max(h - 1, 1) - 1.0
-    return F.grid_sample(x, torch.stack((nx, ny), dim=3), mode="bilinear",
+    return F.grid_sample(_f32(x), _f32(torch.stack((nx, ny), dim=3)), mode="bilinear",
                          padding_mode="border", align_corners=True)
 
 
@@ -230,7 +289,7 @@ class DCN(nn.Module):
         self.deformable_groups = deformable_groups
         self.weight = nn.Parameter(torch.zeros(cout, cin, k, k))
         self.bias = nn.Parameter(torch.zeros(cout))
-        self.conv_offset_mask = nn.Conv2d(cin, deformable_groups * 3 * k * k, k, stride, padding)
+        self.conv_offset_mask = Conv2d(cin, deformable_groups * 3 * k * k, k, stride, padding)
 
     def offsets_and_mask(self, y):
         o = self.conv_offset_mask(y)
@@ -253,7 +312,7 @@ class FeaExtra(nn.Module):
 
     def __init__(self, num_block):
         super().__init__()
-        self.conv_first = nn.Conv2d(3, 64, 3, 1, 1)
+        self.conv_first = Conv2d(3, 64, 3, 1, 1)
         self.residual_layer = res_stack(num_block)
 
     def forward(self, x):
@@ -271,19 +330,19 @@ class OffsetGen(nn.Module):
         self.feat_fusion = nn.ModuleDict()
         for i in (3, 2, 1):
             lv = f"l{i}"
-            self.offset_conv11[lv] = nn.Conv2d(nf * 2, nf, 3, 1, 1)
-            self.offset_conv11_1[lv] = nn.Conv2d(nf, nf, 3, 1, 1)
-            self.offset_conv12[lv] = nn.Conv2d(nf, nf, 3, 1, 1)      # l2/l1 are dead params
+            self.offset_conv11[lv] = Conv2d(nf * 2, nf, 3, 1, 1)
+            self.offset_conv11_1[lv] = Conv2d(nf, nf, 3, 1, 1)
+            self.offset_conv12[lv] = Conv2d(nf, nf, 3, 1, 1)      # l2/l1 are dead params
             if i < 3:
-                self.feat_fusion[lv] = nn.Conv2d(nf * 2, nf, 1, 1, 0)
-        self.upsample_conv = nn.Conv2d(nf, nf, 3, 1, 1)
-        self.conv_l2_1 = nn.Conv2d(nf, nf, 3, 2, 1)
-        self.conv_l2_2 = nn.Conv2d(nf, nf, 3, 1, 1)
-        self.conv_l3_1 = nn.Conv2d(nf, nf, 3, 2, 1)
-        self.conv_l3_2 = nn.Conv2d(nf, nf, 3, 1, 1)
+                self.feat_fusion[lv] = Conv2d(nf * 2, nf, 1, 1, 0)
+        self.upsample_conv = Conv2d(nf, nf, 3, 1, 1)
+        self.conv_l2_1 = Conv2d(nf, nf, 3, 2, 1)
+        self.conv_l2_2 = Conv2d(nf, nf, 3, 1, 1)
+        self.conv_l3_1 = Conv2d(nf, nf, 3, 2, 1)
+        self.conv_l3_2 = Conv2d(nf, nf, 3, 1, 1)
         self.spynet = SPyNet()
         self.attn = SELayer(64)
-        self.feat_fusion_ = nn.Conv2d(nf, nf, 3, 1, 1)
+        self.feat_fusion_ = Conv2d(nf, nf, 3, 1, 1)
 
     def pyramid(self, f):
         a = lambda t: F.leaky_relu(t, 0.1)
@@ -318,12 +377,14 @@ class MCNet(nn.Module):
         super().__init__()
         self.dconv = DCN(64, 64, 3, stride=1, padding=1, deformable_groups=8)
         self.recon_layer = res_stack(num_block)
-        self.feat_down = nn.Conv2d(64, 3, 3, 1, 1)      # dead param
-        self.conv = nn.Conv2d(128, 64, 3, 1, 1)
+        self.feat_down = Conv2d(64, 3, 3, 1, 1)      # dead param
+        self.conv = Conv2d(128, 64, 3, 1, 1)
 
     def forward(self, offset, ref):
         # DCN output is fp16; LeakyReLU then runs on the fp16 tensor; cat/add promote to fp32
-        out = F.leaky_relu(self.dconv(ref, offset), 0.1).float()
+        out = F.leaky_relu(self.dconv(ref, offset), 0.1)
+        if not _Amp.on:
+            out = out.float()          # CPU path: cat / add with the fp32 features promote (under AMP everything here is fp16)
         out2 = F.leaky_relu(self.conv(torch.cat([out, ref], 1)), 0.1)
         return out + self.recon_layer(out2)
 
@@ -333,10 +394,10 @@ class Bottleneck3D(nn.Module):
 
     def __init__(self):
         super().__init__()
-        self.conv1 = nn.Conv3d(64, 64, (1, 3, 3), padding=(0, 1, 1))
-        self.spatial_conv3d = nn.Conv3d(64, 64, (1, 3, 3), padding=(0, 1, 1))
-        self.temporal_conv3d = nn.Conv3d(64, 64, (3, 1, 1), stride=(3, 1, 1), bias=False)
-        self.conv3 = nn.Conv3d(64, 64, (1, 3, 3), padding=(0, 1, 1))
+        self.conv1 = Conv3d(64, 64, (1, 3, 3), padding=(0, 1, 1))
+        self.spatial_conv3d = Conv3d(64, 64, (1, 3, 3), padding=(0, 1, 1))
+        self.temporal_conv3d = Conv3d(64, 64, (3, 1, 1), stride=(3, 1, 1), bias=False)
+        self.conv3 = Conv3d(64, 64, (1, 3, 3), padding=(0, 1, 1))
 
     def forward(self, x):
         o = F.leaky_relu(self.conv1(x), 0.1)
@@ -350,12 +411,12 @@ class LoopFilter(nn.Module):
 
     def __init__(self):
         super().__init__()
-        self.conv01 = nn.Conv2d(3, 64, 3, 1, 1)
-        self.conv02 = nn.Conv2d(64, 64, 3, 1, 1)
-        self.conv1 = nn.Conv3d(64, 64, (1, 3, 3), padding=(0, 1, 1))
+        self.conv01 = Conv2d(3, 64, 3, 1, 1)
+        self.conv02 = Conv2d(64, 64, 3, 1, 1)
+        self.conv1 = Conv3d(64, 64, (1, 3, 3), padding=(0, 1, 1))
         self.layer1 = Bottleneck3D()
         self.attn = SELayer(64)
-        self.feat_fusion = nn.Conv2d(256, 64, 1, 1)
+        self.feat_fusion = Conv2d(256, 64, 1, 1)
 
     def forward(self, pred, refs):
         r = refs[:, 1:]
@@ -373,9 +434,9 @@ class FeatureExtract(nn.Module):
 
     def __init__(self, cin, mid, nblocks):
         super().__init__()
-        self.conv_first = nn.Conv2d(cin, mid, 3, 1, 1)
+        self.conv_first = Conv2d(cin, mid, 3, 1, 1)
         self.body = res_stack(nblocks, mid)
-        self.conv_last = nn.Conv2d(mid, mid, 3, 1, 1)
+        self.conv_last = Conv2d(mid, mid, 3, 1, 1)
 
     def forward(self, x):
         x1 = F.leaky_relu(self.conv_first(x))
@@ -391,13 +452,13 @@ class FeatureFix(nn.Module):
         self.FeatureExtract_input = FeatureExtract(64, 64, 2)
         self.FeatureExtract_ref = FeatureExtract(3, 64, 2)
         self.recon_layer = res_stack(2)
-        self.conv_10 = nn.Conv2d(64, 64, 3, 2, 1)   # conv_10..13: dead params
-        self.conv_11 = nn.Conv2d(64, 64, 3, 1, 1)
-        self.conv_12 = nn.Conv2d(64, 64, 3, 2, 1)
-        self.conv_13 = nn.Conv2d(64, 64, 3, 1, 1)
-        self.featfusion = nn.Conv2d(128, 64, 3, 1, 1)
-        self.featfusion2 = nn.Conv2d(128, 64, 3, 1, 1)
-        self.featdown = nn.Conv2d(64, 3, 3, 1, 1)
+        self.conv_10 = Conv2d(64, 64, 3, 2, 1)   # conv_10..13: dead params
+        self.conv_11 = Conv2d(64, 64, 3, 1, 1)
+        self.conv_12 = Conv2d(64, 64, 3, 2, 1)
+        self.conv_13 = Conv2d(64, 64, 3, 1, 1)
+        self.featfusion = Conv2d(128, 64, 3, 1, 1)
+        self.featfusion2 = Conv2d(128, 64, 3, 1, 1)
+        self.featdown = Conv2d(64, 3, 3, 1, 1)
         self.attn = SELayer(64)
 
     def match(self, fin, fref, scale):
@@ -407,6 +468,7 @@ class FeatureFix(nn.Module):
         pref = F.avg_pool2d(fref, scale, scale)
         a = F.unfold(pin, 3, padding=3, stride=3).transpose(2, 1)            # (N, L, C*9)
         b = F.unfold(pref, 3, padding=3, stride=3).transpose(2, 1).reshape(N, -1, C * 9)
+        a, b = _f32(a), _f32(b)          # AMP emulation: fp32 similarity of the fp16-valued pooled features (module docstring)
         sim = torch.bmm(F.normalize(a, dim=2), F.normalize(b.transpose(2, 1), dim=1))
         _, ind = sim.max(dim=2, keepdim=True)
         ks = 3 * scale
@@ -424,7 +486,7 @@ class FeatureFix(nn.Module):
         scale = 8 if self.training else int(fin.shape[2] / 8)
         ind, out = self.match(fin, fref, scale)
         self.last_match_index = ind          # (N, L) argmax per input patch: what the parity tests compare bit for bit
-        cor = F.cosine_similarity(fin, out).unsqueeze(1)
+        cor = F.cosine_similarity(_f32(fin), _f32(out)).unsqueeze(1)
         o = F.leaky_relu(self.featfusion(torch.cat([fin, out], 1) * cor), 0.1)
         o = F.leaky_relu(self.attn(self.featfusion2(torch.cat([o, fref], 1))), 0.1)
         o = self.recon_layer(o)

@@ -360,7 +360,7 @@ class LoopFilter(nn.Module, PackCache):
         else:
             self._slices("b1", l1.conv1, a, bf, **lr)
             self._slices("bs", l1.spatial_conv3d, bf, s)
-        if ops.TAPE is None and LOOPFILTER_BCAST and B * H * W >= 8192:
+        if ops.TAPE is None and LOOPFILTER_BCAST and H * W >= 8192:      # per IMAGE: conv_v5_eligible (csrc/conv_mfma_v5.hip) counts one map
             # inference: temporal (3,1,1) conv over frames 0-2 + `out + temporal` + LeakyReLU (pnet.py:304-314) as ONE pass over
             # the 4-frame buffer: a wave computes the 64 temporal channels of its pixels and rewrites their four slices in place
             ops.conv(s.ch(0, 192), pk_conv(self, "bt", l1.temporal_conv3d), out=s.ch(0, 64), bcast_T=4, bcast_slope=0.1)
