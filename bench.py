@@ -87,10 +87,10 @@ def cpu_baseline(sample_hw=(HP, WP)):
     from oracle.tdvc_ref import VideoCompressor as Ref
     from tdvc_amd.synth import fill_parameters, make_gop, ref_list
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))      # a 1-GPU box's CPU share is 16 cores; more threads only oversubscribe
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))      # a 1-GPU box's CPU share is 16 cores; more threads only oversubscribe
     torch.set_num_threads(cores)
     ref = Ref().eval()
     fill_parameters(ref)
@@ -104,24 +104,87 @@ def cpu_baseline(sample_hw=(HP, WP)):
     refs = ref_list([g[0:1]])
     with torch.no_grad():
         t0 = time.time()
-        ref(g[1:2], refs, False)
+        ro, bro, bmo = ref(g[1:2], refs, False)
         dt = time.time() - t0
     frac = (h * w) / float(HP * WP)
+    cpu_baseline.last = {"full": full, "recon": ro, "bpp": float(bro + bmo), "x": g[1:2]}       # for the `parity` field of the line
     return {"value": round(frac / dt, 5), "unit": "1080p P-frames/s" + ("" if full else " (area-scaled)"), "cores": torch.get_num_threads(),
+            "host_cores": os.cpu_count(), "cores_available_to_this_process": avail,
             "kind": "port", "seconds": round(dt, 2),
             "sample": ("1 P-frame forward (cfg-2 frame 1, seed 1234) of the fp32 PyTorch oracle at the full 1088x1920" if full else
                        f"1 P-frame forward of the fp32 PyTorch oracle at {h}x{w} ({frac:.3f} of the 1088x1920 pixels), fps scaled by area")}
 
 
-# The three MFMA conv kernels that carry the frame, each with the layer shape behind most of its launches (its
-# "representative launch": 154 GFLOP per conv everywhere) and the committed rocprofv3 --pmc summary of that launch
+def hip_parity_frame(model):
+    """the frame `cpu_baseline` codes (cfg-2 frame 1, seed 1234, reference list [I, I, I, I]) on the HIP path, both coder modes:
+    -> {mode: (recon on the host, bpp)}"""
+    import torch.nn.functional as F
+    from tdvc_amd.synth import make_gop, ref_list
+    g = F.pad(make_gop(1234, 2, 1080, 1920), (0, 0, 4, 4)).cuda()
+    refs = ref_list([g[0:1]])
+    out = {}
+    with torch.no_grad():
+        for mode, amp in (("default", True), ("fp32_islands", False)):
+            r, br, bm = model(g[1:2], refs, amp)
+            out[mode] = (r.float().cpu(), float(br + bm))
+    return out
+
+
+def parity_record(hip):
+    """PSNR / rate of the HIP path minus the CPU oracle's on the frame both coded (north_star: within 0.02 dB / 0.001 bpp)"""
+    import math
+    o = getattr(cpu_baseline, "last", None)
+    if not o or not o["full"] or not hip:
+        return None
+    crop = lambda t: t[:, :, 4:-4]                      # utils.crop: the 1080 visible rows (tools/predict.py:69-70,87)
+    ps = lambda a: 10 * math.log10(1.0 / float(((crop(a) - crop(o["x"])) ** 2).mean()))
+    rec = {"oracle": "fp32 CPU oracle (oracle/tdvc_ref), closed-form filler weights, cfg-2 frame 1 at 1088x1920, PSNR on the 1080 visible rows",
+           "oracle_psnr": round(ps(o["recon"]), 4), "oracle_bpp": round(o["bpp"], 5), "gates": {"dpsnr": 0.02, "dbpp": 0.001}}
+    for mode, (r, b) in hip.items():
+        rec[mode] = {"dpsnr": round(ps(r) - ps(o["recon"]), 5), "dbpp": round(b - o["bpp"], 6)}
+    rec["dpsnr"], rec["dbpp"], rec["mode"] = rec["default"]["dpsnr"], rec["default"]["dbpp"], "default (fp16-in / fp32-accumulate coders)"
+    rec["trained_point"] = ("raw fp32 checkpoint at a trained operating point against the AMP-emulating oracle, one frame and a closed-loop GOP: "
+                            "tests/test_model_gpu.py::test_trained_raw_checkpoint_parity_amp_oracle*, ::test_trained_closed_loop_gop; numbers in DESIGN.md section 4")
+    return rec
+
+
+def rank_identity(rank, local, dev):
+    """what proves that RCCL saw N different devices: (rank, local device, device name, UUID / PCI id, RCCL version)"""
+    pr = torch.cuda.get_device_properties(dev)
+    uuid = str(getattr(pr, "uuid", "")) or None
+    pci = None
+    if hasattr(pr, "pci_bus_id"):
+        pci = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{getattr(pr, 'pci_device_id', 0):02x}"
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:                                    # noqa: BLE001
+        ver = None
+    return {"rank": rank, "local_device": local, "name": pr.name, "uuid": uuid, "pci": pci, "rccl": ver, "host": socket.gethostname()}
+
+
+def gather_ranks(dist, me, world):
+    """all-gather the rank identities (RCCL when there is a process group); rank 0 checks that the devices are distinct"""
+    if dist is None:
+        return [me]
+    got = [None] * world
+    dist.all_gather_object(got, me)
+    keys = [(g_["host"], g_["uuid"] or g_["pci"] or g_["local_device"]) for g_ in got]
+    if len(set(keys)) != world:
+        raise SystemExit(f"bench.py: {world} ranks but only {len(set(keys))} distinct devices: {got}")
+    return got
+
+
+# The MFMA conv kernels that carry the frame, each with the layer shape behind most of its launches (its "representative
+# launch") and the single-launch tool whose rocprofv3 --pmc passes measure its HBM traffic in this run
 REP_LAUNCHES = {
-    "conv_mfma_v10": dict(kind="conv", cin=64, cout=64, H=HP, W=WP, pmc="profiles/r02_conv3x3_64_64_1080p_pmc.txt",
-                          what="3x3 64->64 stride 1 @1088x1920"),
-    "conv_pair": dict(kind="pair", cin=64, cout=64, H=HP, W=WP, pmc="profiles/r02_conv_pair_1080p_pmc.txt",
-                      what="Res_Block = 2 x (3x3 64->64) fused @1088x1920"),
-    "conv_mfma_v11": dict(kind="conv", cin=128, cout=128, H=HP // 2, W=WP // 2, pmc="profiles/r02_conv3x3_128_128_544x960_pmc.txt",
-                          what="3x3 128->128 stride 1 @544x960"),
+    "conv_pair": dict(kind="pair", cin=64, cout=64, H=HP, W=WP, pmc="profiles/r02_conv_pair_1080p_pmc.txt", match="conv_pair",
+                      tool=["one_pair.py", str(HP), str(WP), "6"], what="Res_Block = 2 x (3x3 64->64) fused @1088x1920"),
+    "conv_row": dict(kind="conv", cin=128, cout=128, H=HP // 2, W=WP // 2, pmc=None, match="conv_row",
+                     tool=["one_conv.py", "128", "128", "3", "1", str(HP // 2), str(WP // 2), "6"], what="3x3 128->128 stride 1 @544x960"),
+    "conv_mfma_v11": dict(kind="conv", cin=128, cout=64, H=HP, W=WP, pmc=None, match="conv_mfma_v11",
+                          tool=["one_conv.py", "128", "64", "3", "1", str(HP), str(WP), "6"], what="3x3 128->64 stride 1 @1088x1920"),
+    "conv_mfma_v10": dict(kind="conv", cin=64, cout=216, H=HP, W=WP, pmc=None, match="conv_mfma_v10",
+                          tool=["one_conv.py", "64", "216", "3", "1", str(HP), str(WP), "6"], what="3x3 64->216 stride 1 @1088x1920 (conv_offset_mask)"),
 }
 
 
@@ -145,16 +208,17 @@ def pmc_traffic_bytes(pmc_file=PMC_FILE):
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
 
 
-def measure_pair_traffic():
-    """HBM bytes per launch of the dominant kernel's representative launch (conv_pair, Res_Block @1088x1920), MEASURED in this
-    run: two `rocprofv3 --pmc` child processes (FETCH_SIZE and WRITE_SIZE need passes of their own: MI355X_MICROARCH.md,
-    rocprofv3 PMC slots) on tools/one_pair.py, started BEFORE this process touches the GPU (a GPU-initialised process
-    starts no child).  gfx950 correction of the guide: a wide coalesced read reports half its bytes -> 2 x FETCH_SIZE.
+def measure_traffic(kname):
+    """HBM bytes per launch of kernel `kname`'s representative launch (REP_LAUNCHES), MEASURED in this run: two `rocprofv3 --pmc`
+    child processes (FETCH_SIZE and WRITE_SIZE need passes of their own: MI355X_MICROARCH.md, rocprofv3 PMC slots) on its
+    single-launch tool, started BEFORE this process touches the GPU (a GPU-initialised process starts no child).  gfx950
+    correction of the guide: a wide coalesced read reports half its bytes -> 2 x FETCH_SIZE.
     -> (bytes per launch, description) or (None, reason)."""
     import csv
     import glob
     import shutil
     import tempfile
+    L = REP_LAUNCHES[kname]
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None, "rocprofv3 not found"
@@ -164,22 +228,22 @@ def measure_pair_traffic():
         out = tempfile.mkdtemp(prefix="tdvc_pmc_", dir="/tmp")
         try:
             r = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "r", "--", sys.executable,
-                                os.path.join(ROOT, "tools", "one_pair.py"), str(HP), str(WP), "6"], cwd="/tmp", env=env,
+                                os.path.join(ROOT, "tools", L["tool"][0])] + L["tool"][1:], cwd="/tmp", env=env,
                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode})"
             v = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
-                 if "conv_pair" in row["Kernel_Name"] and row["Counter_Name"] == ctr]
+                 if L["match"] in row["Kernel_Name"] and row["Counter_Name"] == ctr]
             if not v:
-                return None, f"no conv_pair rows in the {ctr} pass"
+                return None, f"no {L['match']} rows in the {ctr} pass"
             vals[ctr] = sum(v) / len(v)
         except Exception as ex:                                  # never lose the headline line to the profiler
             return None, f"{type(ex).__name__}: {ex}"[:200]
         finally:
             shutil.rmtree(out, ignore_errors=True)
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, (
-        f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes on tools/one_pair.py {HP} {WP} before the timed region "
+        f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes on tools/{' '.join(L['tool'])} before the timed region "
         f"(FETCH_SIZE {vals['FETCH_SIZE']:.0f} KB x 2 [gfx950 wide-read correction] + WRITE_SIZE {vals['WRITE_SIZE']:.0f} KB)")
 
 
@@ -282,7 +346,7 @@ def roofline_leg(runner):
         _time_launches(fn, 10)                             # the first timed loop of a process runs slow (clock ramp)
         ms = sorted(_time_launches(fn) for _ in range(3))[1]        # median of three loops of 20 back-to-back launches
         ach = flop / (ms * 1e-3) / 1e12
-        traffic = pmc_traffic_bytes(L["pmc"])
+        traffic = pmc_traffic_bytes(L["pmc"]) if L["pmc"] else None
         tsrc = (L["pmc"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; not measured in this run)") if traffic else None
         if kname in LIVE_TRAFFIC and LIVE_TRAFFIC[kname][0]:
             traffic, tsrc = LIVE_TRAFFIC[kname]
@@ -294,10 +358,10 @@ def roofline_leg(runner):
                 "frame_kernel": {"launches_per_frame": agg[kname]["n"], "ms_per_frame": round(agg[kname]["ms"], 3),
                                  "tflops": round(agg[kname]["flops"] / (agg[kname]["ms"] * 1e-3) / 1e12, 2)} if kname in agg else None}
 
-    # the dominant kernel = most milliseconds per frame among the kernels with a representative launch (the three carry
-    # ~60 % of the conv time and sit within 1.5 ms of each other); the other two are reported beside it
+    # the dominant kernel = most milliseconds per frame among the kernels with a representative launch; the others are
+    # reported beside it
     cands = [k for k in REP_LAUNCHES if k in agg]
-    name = max(cands, key=lambda k: agg[k]["ms"]) if cands else "conv_mfma_v10"
+    name = max(cands, key=lambda k: agg[k]["ms"]) if cands else "conv_pair"
     out = {"bound": "mfma"}
     out.update(rep(name))
     out["other_kernels"] = [rep(k) for k in REP_LAUNCHES if k != name]
@@ -385,16 +449,19 @@ def main():
     if world != a.gpus:
         sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if world == 1 and a.mode == "infer" and not a.no_extras and not a.no_pmc:
-        t_, src_ = measure_pair_traffic()                  # child processes: must run before this process initialises the GPU
-        LIVE_TRAFFIC["conv_pair"] = (t_, src_)
-        print(f"[bench] conv_pair traffic: {t_} ({src_})", file=sys.stderr, flush=True)
+        for kname in REP_LAUNCHES:                         # child processes: must run before this process initialises the GPU
+            t_, src_ = measure_traffic(kname)
+            LIVE_TRAFFIC[kname] = (t_, src_)
+            print(f"[bench] {kname} traffic: {t_} ({src_})", file=sys.stderr, flush=True)
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if world > 1 or os.environ.get("TDVC_BENCH_FORCE_DIST") == "1":      # the env flag: a ONE-rank RCCL group (tests exercise this path on one GPU)
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ranks_seen = gather_ranks(dist, rank_identity(rank, local, dev), world)
 
     def finish_dist():
         if dist:
@@ -405,7 +472,9 @@ def main():
         dt, log = train_measure(a.train_batch, a.steps, a.warmup, rank, a.gpus, dev, dist, a.graph)
         finish_dist()
         if rank == 0:
-            print(json.dumps(train_record(a.train_batch, a.steps, a.warmup, a.gpus, dt, log)))
+            rec = train_record(a.train_batch, a.steps, a.warmup, a.gpus, dt, log)
+            rec["ranks_seen"] = ranks_seen
+            print(json.dumps(rec))
         return
 
     model = build_model(dev)
@@ -447,10 +516,14 @@ def main():
         "whole_path_tflops": round(FLOP_PER_PX * HP * WP * fps / a.gpus / 1e12, 2),
         "whole_path_frac_of_mfma_peak": round(FLOP_PER_PX * HP * WP * fps / a.gpus / MFMA_F16_PEAK, 4),
         "bpp_last": round(float(bpp_res + bpp_mv), 5),
+        "ranks_seen": ranks_seen,
         "roofline": roof,
     }
+    hip_par = None
     if a.gpus == 1 and not a.no_extras:
         line["roofline_hbm"] = hbm_rooflines(model)
+        if not a.no_cpu_baseline and a.cpu_sample.lower() == f"{HP}x{WP}":
+            hip_par = hip_parity_frame(model)             # the frame the CPU oracle codes below, both coder modes
         try:                                           # the same frames with both coders as fp32 islands (pnet.py:33,57)
             if not getattr(model, "fp32_islands_supported", False):
                 raise RuntimeError("this build has no fp32-island mode")
@@ -477,6 +550,9 @@ def main():
     if a.gpus == 1 and not a.no_cpu_baseline:
         h, w = (int(v) for v in a.cpu_sample.lower().split("x"))
         line["cpu_baseline"] = cpu_baseline((h, w))
+        par = parity_record(hip_par)
+        if par:
+            line["parity"] = par
     print(json.dumps(line))
 
 

@@ -374,6 +374,26 @@ int tdvc_conv_wgrad_bias(const tdvc_fmap* g, const tdvc_fmap* x, int cout, int k
                          const int32_t* tap_off, int square_x, float scale, float* dw, const int32_t* bias_index, float* db,
                          float* work, int64_t work_floats, void* stream);
 
+/* The two stages apart (training: ~220 layers per step, each reduce a 15 us launch of its own on the side stream): tdvc_conv_wgrad_partials
+ * runs the first stage only and fills `job` (a HOST struct) with what the second stage needs; tdvc_wgrad_reduce_batch runs the second stage
+ * of many layers in ONE launch.  `jobs` and `block_start` (njobs + 1 prefix sums of tdvc_wgrad_reduce_job::nblocks) are DEVICE arrays.
+ * Jobs of one batch must write disjoint dw / db ranges (the sums are `+=` without atomics): a caller with several jobs for one parameter
+ * (shared layers, per-image launches) issues them in successive batches, which also keeps the summation order fixed.  `work` must stay
+ * alive and unmodified until the batch that reduces it has run. */
+typedef struct tdvc_wgrad_reduce_job {
+  const float* work;
+  const float* bwork;
+  const int32_t *row_off, *chan_off, *tap_off, *bias_index;
+  float *dw, *db;
+  float scale;
+  int32_t nworkers, cow, ciw, ntaps, cout, cin, wblocks, nblocks;
+} tdvc_wgrad_reduce_job;
+int tdvc_conv_wgrad_partials(const tdvc_fmap* g, const tdvc_fmap* x, int cout, int kh, int kw, int stride, int pad,
+                             int ntaps, const int8_t* tap_dy, const int8_t* tap_dx, const int32_t* row_off, const int32_t* chan_off,
+                             const int32_t* tap_off, int square_x, float scale, float* dw, const int32_t* bias_index, float* db,
+                             float* work, int64_t work_floats, tdvc_wgrad_reduce_job* job, void* stream);
+int tdvc_wgrad_reduce_batch(const tdvc_wgrad_reduce_job* jobs, const int32_t* block_start, int njobs, int total_blocks, void* stream);
+
 /* out = g * act'(z), ReLU / LeakyReLU, the sign of z taken from the stored output (y - res); out may alias g. */
 int tdvc_act_backward(const tdvc_fmap* g, const tdvc_fmap* y, const tdvc_fmap* res, int act, float slope, const tdvc_fmap* out, void* stream);
 /* out[n][Y][X][(i*2+j)*C + c] = y[n][2Y+i][2X+j][c] (adjoint of the PixelShuffle(2) store, packed-row order). */

@@ -44,6 +44,13 @@ class ConvPairDesc(C.Structure):
                 ("act2", C.c_int32), ("slope2", C.c_float), ("add_input", C.c_int32), ("res2", FMapDesc)]
 
 
+class WgradReduceJob(C.Structure):
+    _fields_ = [("work", C.c_void_p), ("bwork", C.c_void_p), ("row_off", C.c_void_p), ("chan_off", C.c_void_p), ("tap_off", C.c_void_p),
+                ("bias_index", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("scale", C.c_float),
+                ("nworkers", C.c_int32), ("cow", C.c_int32), ("ciw", C.c_int32), ("ntaps", C.c_int32), ("cout", C.c_int32), ("cin", C.c_int32),
+                ("wblocks", C.c_int32), ("nblocks", C.c_int32)]
+
+
 _P = C.c_void_p
 _FM = C.POINTER(FMapDesc)
 _i, _f, _i64 = C.c_int, C.c_float, C.c_int64
@@ -97,6 +104,8 @@ SIGNATURES = {
     "tdvc_conv_wgrad_work_floats": (_i64, [_i] * 6),
     "tdvc_conv_wgrad": (_i, [_FM, _FM] + [_i] * 6 + [_P] * 5 + [_i, _f, _P, _P, _i64, _P]),
     "tdvc_conv_wgrad_bias": (_i, [_FM, _FM] + [_i] * 6 + [_P] * 5 + [_i, _f, _P, _P, _P, _P, _i64, _P]),
+    "tdvc_conv_wgrad_partials": (_i, [_FM, _FM] + [_i] * 6 + [_P] * 5 + [_i, _f, _P, _P, _P, _P, _i64, C.POINTER(WgradReduceJob), _P]),
+    "tdvc_wgrad_reduce_batch": (_i, [_P, _P, _i, _i, _P]),
     "tdvc_gdn_backward": (_i, [_FM, _FM, _FM, _i, _FM, _FM, _P]),
     "tdvc_mul2_accumulate": (_i, [_FM, _FM, _FM, _P]),
     "tdvc_dcn_fused": (_i, [C.POINTER(DcnDesc), _P]),

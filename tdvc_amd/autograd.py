@@ -21,6 +21,9 @@ from . import ops
 from .ops import FM
 
 
+BATCH_WGRAD_REDUCE = True        # A/B switch (tools/ab_train.py): False = one reduce launch per layer, right behind its first stage
+
+
 class MirrorPool:
     """Zeroed gradient-mirror buffers that outlive a step.  A tape takes its mirrors from the pool instead of
     `torch.zeros_like` (211 fills, 1.5 ms of a 35 ms step); after the sweep `recycle()` re-zeroes the used ones on the
@@ -45,8 +48,9 @@ class MirrorPool:
         ev.record(main)
         with torch.cuda.stream(side):
             side.wait_event(ev)
+            if self.used:
+                torch._foreach_zero_([t for _, t in self.used])      # a few multi-tensor launches instead of one fill per mirror (211 per step)
             for key, t in self.used:
-                t.zero_()
                 self.free.setdefault(key, []).append(t)
         self.used = []
 
@@ -69,6 +73,13 @@ class Tape:
         # stream they run next to the dgrad chain and fill the CUs the small layers leave idle
         self.side = None
         self.pool: MirrorPool | None = None       # persistent zeroed mirrors (TrainStep, eager mode)
+        # second stages of the weight gradients, reduced in one launch per join() instead of one per layer (ops.WgradBatch)
+        self.wbatch = ops.WgradBatch() if BATCH_WGRAD_REDUCE else None
+        # parameter-space chains that run as torch kernels (the entropy bottleneck's softplus / tanh chain, the GDN reparametrisation):
+        # executed after the sweep AND after join(), when no MFMA kernel runs on the side stream any more -- torch's own device code is
+        # built WITH packed-FP32 instructions, and its softplus kernels contain the `v_pk_*_f32 ... op_sel:[0,1]` form that returned
+        # wrong values next to a concurrent MFMA stream (profiles/r04_torch_packed_fp32_scan.txt)
+        self.deferred: list = []
 
     # ------------------------------------------------------------------ gradient views
     def _base(self, t: torch.Tensor) -> torch.Tensor:
@@ -96,6 +107,10 @@ class Tape:
     def add(self, fn):
         self.nodes.append(fn)
 
+    def defer(self, fn):
+        """run `fn` at the end of backward(), behind join(); it counts as one more backward node (index n_backward_nodes) for touch()"""
+        self.deferred.append(fn)
+
     def off_path(self, fn, *tensors):
         """run `fn` (parameter-gradient kernels reading `tensors`) on the side stream, ordered after everything issued so far"""
         if self.side is None:
@@ -115,6 +130,7 @@ class Tape:
         """drop every reference the tape holds (closures, mirrors, kept operands, hooks): the hook closures refer back to
         the tape, so without this a finished tape — and the ~4 GB of activations it pins — waits for the cyclic GC"""
         self.nodes.clear()
+        self.deferred.clear()
         self.gbuf.clear()
         self.keep.clear()
         self.on_node_done = None
@@ -122,7 +138,14 @@ class Tape:
         self.pool = None
 
     def join(self):
-        """the main stream waits for the parameter-gradient kernels (before an all-reduce, the optimizer, the tape's end)"""
+        """the main stream waits for the parameter-gradient kernels (before an all-reduce, the optimizer, the tape's end); the deferred
+        reduce stages of the weight gradients collected so far go out first, on the stream their first stages ran on"""
+        if self.wbatch is not None and self.wbatch.items:
+            if self.side is not None:
+                with torch.cuda.stream(self.side):
+                    self.wbatch.flush()
+            else:
+                self.wbatch.flush()
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
 
@@ -146,11 +169,16 @@ class Tape:
                 fn()
                 if self.on_node_done is not None:
                     self.on_node_done(k)
+            self.join()
+            self._cur = self.n_backward_nodes                 # the deferred chains: one virtual node behind the sweep
+            for fn in self.deferred:
+                fn()
         finally:
             self.join()
             ops._IN_BACKWARD = prev
             self._cur = -1
         self.nodes.clear()
+        self.deferred.clear()
 
 
 def param_grad(p: torch.Tensor) -> torch.Tensor:
@@ -208,7 +236,8 @@ def record_conv(tape: Tape, x: FM, pc, y, act, slope, res, res2, gdn, aux, squar
             raise NotImplementedError(f"autograd: activation {act}")
         gq = ops.pixel_unshuffle(g) if pc.shuffle else g
         tape.off_path(lambda: ops.conv_wgrad(pc, gq, x, param_grad(weight).view(-1), scale=tape.inv_scale,
-                                             db=param_grad(bias) if bias is not None else None),     # bias gradient from the same launch
+                                             db=param_grad(bias) if bias is not None else None,      # bias gradient from the same launch
+                                             defer=tape.wbatch),                                     # its reduce stage: batched at join()
                       gq.t, x.t)
         if tape.needs_grad(x):
             ops.conv_dgrad(pc, gq, tape.grad(x), accumulate=True)
@@ -328,8 +357,11 @@ def record_gdn(tape: Tape, x: FM, pc, y: FM, res, gdn):
         dgamma = torch.zeros_like(pc.wsrc)
         dbeta = torch.zeros_like(pc.bsrc)
         ops.conv_wgrad(pc, dn, x, dgamma.view(-1), scale=tape.inv_scale, square_x=True, db=dbeta)
-        owner.accumulate_param_grads(dgamma.view(dgamma.shape[0], dgamma.shape[1]), dbeta)
-        tape.touch(*owner.parameters())
+
+        def chain():                              # torch autograd through the reparametrisation: behind the sweep (Tape.defer)
+            owner.accumulate_param_grads(dgamma.view(dgamma.shape[0], dgamma.shape[1]), dbeta)
+            tape.touch(*owner.parameters())
+        tape.defer(chain)
 
     tape.add(bwd)
 
@@ -344,8 +376,11 @@ def record_eb_forward(tape: Tape, z: FM, params: torch.Tensor, z_hat: FM, noise)
         accumulate(dz, tape.grad(z_hat))          # z_hat = z + noise
         dp = torch.zeros_like(params)
         ops.eb_backward(z, params, noise, tape.rate_grad * tape.loss_scale, dz, dp)
-        owner.accumulate_param_grads(dp * tape.inv_scale)
-        tape.touch(*owner.parameters())
+
+        def chain():                              # softplus / tanh chain to the raw parameters as torch kernels: behind the sweep (Tape.defer)
+            owner.accumulate_param_grads(dp * tape.inv_scale)
+            tape.touch(*owner.parameters())
+        tape.defer(chain)
 
     tape.add(bwd)
 

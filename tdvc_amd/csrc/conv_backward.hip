@@ -337,15 +337,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 // dW[row_off[co] + chan_off[ci] + tap_off[t]] += scale * sum over workers (fixed order); the tables are the layer's
 // forward packing tables (convpack.forward_tables), so PixelShuffle row order, concatenation channel order,
 // zero-padded channels and Conv3d holders scatter to the right parameter element
-__global__ void wgrad_reduce_kernel(const float* __restrict__ work, int nworkers, int COW, int CIW, int ntaps, const int* __restrict__ row_off,
-                                    const int* __restrict__ chan_off, const int* __restrict__ tap_off, int cout, int cin, float scale,
-                                    float* __restrict__ dw, int wblocks, const float* __restrict__ bwork,
-                                    const int* __restrict__ bias_index, float* __restrict__ db) {
+__device__ __forceinline__ void wgrad_reduce_block(int blk, const float* __restrict__ work, int nworkers, int COW, int CIW, int ntaps,
+                                                   const int* __restrict__ row_off, const int* __restrict__ chan_off, const int* __restrict__ tap_off,
+                                                   int cout, int cin, float scale, float* __restrict__ dw, int wblocks, const float* __restrict__ bwork,
+                                                   const int* __restrict__ bias_index, float* __restrict__ db) {
   // 64 elements per workgroup, 4 worker slices per element (fixed order: the sum is reproducible)
   __shared__ float part[4][64];
   const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  if ((int)blockIdx.x >= wblocks) {                         // bias gradient: db[index[co]] += scale * sum_w bwork[w][co]
-    const int co = ((int)blockIdx.x - wblocks) * 64 + e;
+  if (blk >= wblocks) {                                     // bias gradient: db[index[co]] += scale * sum_w bwork[w][co]
+    const int co = (blk - wblocks) * 64 + e;
     float s = 0.f;
     if (co < cout)
       for (int w = sl; w < nworkers; w += 4) s += bwork[(long)w * COW + co];
@@ -356,7 +356,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ work, int nworkers
     if (d >= 0) db[d] += ((part[0][e] + part[1][e]) + (part[2][e] + part[3][e])) * scale;
     return;
   }
-  const long i = (long)blockIdx.x * 64 + e;
+  const long i = (long)blk * 64 + e;
   const long total = (long)cout * cin * ntaps;
   const bool live = i < total;
   const int ci = live ? (int)(i % cin) : 0;               // fastest index = ci: coalesced reads of the partials
@@ -376,6 +376,26 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ work, int nworkers
   if (ro < 0 || cf < 0) return;
   s = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
   dw[(long)ro + cf + tap_off[t]] += s * scale;
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ work, int nworkers, int COW, int CIW, int ntaps, const int* __restrict__ row_off,
+                                    const int* __restrict__ chan_off, const int* __restrict__ tap_off, int cout, int cin, float scale,
+                                    float* __restrict__ dw, int wblocks, const float* __restrict__ bwork,
+                                    const int* __restrict__ bias_index, float* __restrict__ db) {
+  wgrad_reduce_block((int)blockIdx.x, work, nworkers, COW, CIW, ntaps, row_off, chan_off, tap_off, cout, cin, scale, dw, wblocks, bwork, bias_index, db);
+}
+
+// The second stage of MANY layers in one launch: block_start[j] .. block_start[j + 1] are the blocks of job j (same arithmetic and
+// summation order as wgrad_reduce_kernel: bit-identical gradients)
+__global__ void wgrad_reduce_batch_kernel(const tdvc_wgrad_reduce_job* __restrict__ jobs, const int* __restrict__ block_start, int njobs) {
+  int lo = 0, hi = njobs;                                              // last job with block_start <= blockIdx.x
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (block_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const tdvc_wgrad_reduce_job j = jobs[lo];
+  wgrad_reduce_block((int)blockIdx.x - block_start[lo], j.work, j.nworkers, j.cow, j.ciw, j.ntaps, j.row_off, j.chan_off, j.tap_off, j.cout, j.cin,
+                     j.scale, j.dw, j.wblocks, j.bwork, j.bias_index, j.db);
 }
 
 }  // namespace
@@ -432,10 +452,11 @@ extern "C" int64_t tdvc_conv_wgrad_work_floats(int cout, int cin, int ntaps, int
   return (int64_t)wgrad_workers(co_tiles, ci_tiles, groups, nblocks, ntaps) * co_tiles * WG_CO * (ci_tiles * WG_CI * ntaps + 1);   // + bias partials
 }
 
-extern "C" int tdvc_conv_wgrad_bias(const tdvc_fmap* g, const tdvc_fmap* x, int cout, int kh, int kw, int stride, int pad,
-                                    int ntaps, const int8_t* tap_dy, const int8_t* tap_dx, const int32_t* row_off, const int32_t* chan_off,
-                                    const int32_t* tap_off, int square_x, float scale, float* dw, const int32_t* bias_index, float* db,
-                                    float* work, int64_t work_floats, void* stream) {
+extern "C" int tdvc_conv_wgrad_partials(const tdvc_fmap* g, const tdvc_fmap* x, int cout, int kh, int kw, int stride, int pad,
+                                        int ntaps, const int8_t* tap_dy, const int8_t* tap_dx, const int32_t* row_off, const int32_t* chan_off,
+                                        const int32_t* tap_off, int square_x, float scale, float* dw, const int32_t* bias_index, float* db,
+                                        float* work, int64_t work_floats, tdvc_wgrad_reduce_job* job, void* stream) {
+  TDVC_CHECK(job, "tdvc_conv_wgrad_partials: null job");
   TDVC_CHECK(g && x && dw && work && tap_dy && tap_dx && row_off && chan_off && tap_off, "tdvc_conv_wgrad: null pointer");
   TDVC_CHECK(fmap_ok16(*g) && fmap_ok16(*x) && g->N == x->N, "tdvc_conv_wgrad: fmaps must be fp16 with matching batch");
   TDVC_CHECK(stride == 1 || stride == 2, "tdvc_conv_wgrad: stride %d", stride);
@@ -480,8 +501,30 @@ extern "C" int tdvc_conv_wgrad_bias(const tdvc_fmap* g, const tdvc_fmap* x, int 
   if (rc) return rc;
   const long total = (long)cout * cin * ntaps;
   const int wblocks = (int)((total + 63) / 64), bblocks = db ? (cout + 63) / 64 : 0;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(wblocks + bblocks)), dim3(256), 0, st, work, workers, p.co_tiles * WG_CO,
-                     p.ci_tiles * WG_CI, ntaps, row_off, chan_off, tap_off, cout, cin, scale, dw, wblocks, p.bwork, bias_index, db);
+  job->work = work; job->bwork = p.bwork;
+  job->row_off = row_off; job->chan_off = chan_off; job->tap_off = tap_off; job->bias_index = bias_index;
+  job->dw = dw; job->db = db; job->scale = scale;
+  job->nworkers = workers; job->cow = p.co_tiles * WG_CO; job->ciw = p.ci_tiles * WG_CI; job->ntaps = ntaps; job->cout = cout; job->cin = cin;
+  job->wblocks = wblocks; job->nblocks = wblocks + bblocks;
+  return tdvc_launch_status("tdvc_conv_wgrad");
+}
+
+extern "C" int tdvc_wgrad_reduce_batch(const tdvc_wgrad_reduce_job* jobs, const int32_t* block_start, int njobs, int total_blocks, void* stream) {
+  TDVC_CHECK(jobs && block_start && njobs >= 1 && total_blocks >= 1, "tdvc_wgrad_reduce_batch: bad arguments");
+  hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), jobs, block_start, njobs);
+  return tdvc_launch_status("tdvc_wgrad_reduce_batch");
+}
+
+extern "C" int tdvc_conv_wgrad_bias(const tdvc_fmap* g, const tdvc_fmap* x, int cout, int kh, int kw, int stride, int pad,
+                                    int ntaps, const int8_t* tap_dy, const int8_t* tap_dx, const int32_t* row_off, const int32_t* chan_off,
+                                    const int32_t* tap_off, int square_x, float scale, float* dw, const int32_t* bias_index, float* db,
+                                    float* work, int64_t work_floats, void* stream) {
+  tdvc_wgrad_reduce_job j;
+  const int rc = tdvc_conv_wgrad_partials(g, x, cout, kh, kw, stride, pad, ntaps, tap_dy, tap_dx, row_off, chan_off, tap_off, square_x, scale, dw,
+                                          bias_index, db, work, work_floats, &j, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)j.nblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), j.work, j.nworkers, j.cow,
+                     j.ciw, j.ntaps, j.row_off, j.chan_off, j.tap_off, j.cout, j.cin, j.scale, j.dw, j.wblocks, j.bwork, j.bias_index, j.db);
   return tdvc_launch_status("tdvc_conv_wgrad");
 }
 

@@ -77,6 +77,12 @@ static_assert((BI & (BI - 1)) == 0 && (XRING & (XRING - 1)) == 0 && LDS_PAIR <= 
 // BI = 4 (2.5 % faster in isolation) fails (1)+(2) with HD = 4: PF >= 8 and PF <= 6.  With HD = 2 / PF = 6 both hold and the
 // rings take 155 648 B; measured gain < 1 % on the frame's four-slice launches, so BI = 2 ships.
 constexpr int NTHR = 512;
+// round 4 (from conv_row.hip, tools/ab_row.py): a conv1 wave issues the next row's DMA pieces after the first third of its MFMAs instead
+// of in front of them -- at the top of a step both waves of a SIMD did their non-matrix work side by side in front of an idle matrix pipe --
+// and waits with a constant count: every conv1 wave issues 1 + 1 + 1 + 2 = 5 instructions over any four consecutive issuing steps
+#ifndef PAIR_DMA_MID
+#define PAIR_DMA_MID 1
+#endif
 
 struct PairParams {
   const half_t* x; long x_sn; int x_sp;
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
     };
     // the 36 MFMAs of one row: fragment (cb, dx, kc) x taps (dy, dx); SN / SM / SD: accumulator rows that start here (dy 0,
     // bias as the C operand), continue (dy 1) and finish (dy 2, issued first so that the pack of the finished row overlaps the rest)
-    auto row_mfmas = [&](auto SNc, auto SMc, auto SDc, auto fin) __attribute__((always_inline)) {
+    auto row_mfmas = [&](auto SNc, auto SMc, auto SDc, auto fin, auto mid) __attribute__((always_inline)) {
       constexpr int SN = decltype(SNc)::value, SM = decltype(SMc)::value, SD = decltype(SDc)::value;
 #pragma unroll
       for (int dyo = 0; dyo < 3; ++dyo) {
@@ -255,6 +261,7 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
                                                                      first ? bias4 : acc[slot][cb], 0, 0, 0);
             }
         if (dy == 2) fin();
+        if (dyo == 0) mid();
       }
     };
 
@@ -273,6 +280,11 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
     // k + 4 on); the operations of the last four steps -- their number is tracked exactly -- may stay in flight.  Vector
     // memory operations of a wave complete in order on this architecture (one counter for loads, stores and LDS-DMA).
     auto land_wait = [&](int nvm) __attribute__((always_inline)) {
+#if PAIR_DMA_MID
+      if (nvm) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // shorter histories (first steps) have fewer in flight: no wait, nothing older to wait for
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // issuing has stopped (segment tail)
+      return;
+#endif
       hist = (hist << 8) | (unsigned)nvm;
       const unsigned sum = (hist & 0xFFu) + ((hist >> 8) & 0xFFu) + ((hist >> 16) & 0xFFu) + (hist >> 24);
       switch (sum) {
@@ -305,7 +317,7 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
         int nvm = 0;
         if (FULL || k <= rows + 3) {
           load_frags(X0 + (k & (XRING - 1)) * ROWB);
-          if (k + PF <= rows + 3 && !(p.experiment & 1)) nvm = issue_row(k + PF);
+          if (!PAIR_DMA_MID && k + PF <= rows + 3 && !(p.experiment & 1)) nvm = issue_row(k + PF);
           row_mfmas(S1c{}, S0c{}, S2c{}, [&]() __attribute__((always_inline)) {
             // t row i - 1 -> fp16, activation, zero outside the image, into the t ring
             const int trow = i - 1;
@@ -322,6 +334,8 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
               u[0] &= m; u[1] &= m;
               *reinterpret_cast<u32x2*>(tb + doff[cb]) = u;
             }
+          }, [&]() __attribute__((always_inline)) {
+            if (PAIR_DMA_MID && k + PF <= rows + 3 && !(p.experiment & 1)) nvm = issue_row(k + PF);
           });
         }
         if constexpr (STAMP && FULL) {
@@ -358,7 +372,7 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
               if constexpr (ADDX) h = h + *reinterpret_cast<const half4*>(xb + roff[cb]);
               *reinterpret_cast<half4*>(sb + doff[cb]) = h;
             }
-          });
+          }, []() {});
         }
         if constexpr (STAMP && FULL) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -32,7 +32,9 @@ class VideoCompressor(nn.Module):
         # the reference keeps both coders outside autocast (pnet.py:33,57).  Default here: fp16-in / fp32-accumulate coders
         # (the 30 fps path); `enabled_amp=False` in forward(), or this flag for encode() / decode(), runs them as true fp32
         # islands (fp32 activations + weights on v_mfma_f32_32x32x2_f32): symbols and byte streams then equal the fp32 CPU
-        # reference's on identical coder inputs (tests/test_entropy_coding_gpu.py)
+        # reference's on identical coder inputs (tests/test_entropy_coding_gpu.py).  NOTE for reference checkpoints: the reference's
+        # `enable_amp: True` (cfg/predict.yaml) keeps fp32 coders; here that value selects the fp16-in coders, so the reference-faithful
+        # setting is coder_fp32 = True (tools/predict: yaml key `coder_fp32: true` or --coder-fp32), independent of `enabled_amp`
         self.coder_fp32 = False
         # symbol order of the y streams encode() writes and decode() expects: "raster" (compressai's, what the reference's
         # decoder reads) or "wavefront" (an extension: the decoder takes an anti-diagonal per step instead of a position)

@@ -550,7 +550,51 @@ def conv_dgrad(pc: PackedConv, g: FM, dx: FM, accumulate=True) -> FM:
     return conv(g, dpc, out=dx, res=dx if accumulate else None)
 
 
-def conv_wgrad(pc: PackedConv, g: FM, x: FM, dw: torch.Tensor, scale=1.0, square_x=False, db: torch.Tensor | None = None) -> None:
+class WgradBatch:
+    """Deferred second stages of conv weight gradients (training: ~220 layers per step, each order-fixed reduce a 15 us launch of its own,
+    3.4 ms of the side stream).  `conv_wgrad(..., defer=batch)` runs the first stage only; `flush()` reduces everything collected so far
+    in ONE launch of `tdvc_wgrad_reduce_batch` per round, on the current stream (the one the first stages ran on).  Jobs that add to the
+    same parameter (shared layers, per-image launches of one layer) go to successive rounds in their order of arrival, so the sums and
+    their order are those of the immediate form: bit-identical gradients."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, job, keep):
+        self.items.append((job, keep))
+
+    def flush(self):
+        if not self.items:
+            return
+        rounds, nxt = [], {}
+        for job, _ in self.items:
+            r = nxt.get(job.dw, 0)
+            nxt[job.dw] = r + 1
+            if len(rounds) <= r:
+                rounds.append([])
+            rounds[r].append(job)
+        lib = L.lib()
+        for jobs in rounds:
+            n = len(jobs)
+            arr = (L.WgradReduceJob * n)(*jobs)
+            starts = (C.c_int32 * (n + 1))()
+            for i, j in enumerate(jobs):
+                starts[i + 1] = starts[i] + j.nblocks
+            nb_j, nb_s = C.sizeof(arr), C.sizeof(starts)
+            host = torch.empty((nb_j + nb_s,), dtype=torch.uint8, pin_memory=True)
+            C.memmove(host.data_ptr(), arr, nb_j)
+            C.memmove(host.data_ptr() + nb_j, starts, nb_s)
+            dev = host.to(jobs_device(jobs), non_blocking=True)
+            L.check(lib.tdvc_wgrad_reduce_batch(dev.data_ptr(), dev.data_ptr() + nb_j, n, int(starts[n]), _stream()), "wgrad_reduce_batch")
+        self.items.clear()
+
+
+def jobs_device(jobs):
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def conv_wgrad(pc: PackedConv, g: FM, x: FM, dw: torch.Tensor, scale=1.0, square_x=False, db: torch.Tensor | None = None,
+               defer: WgradBatch | None = None) -> None:
     """dW += scale * dL/dW (fp32, the parameter's own layout); `g` as in conv_dgrad.  With `db` the bias gradient
     (what `conv_bgrad` computes) comes out of the same launch: the kernel already holds the dY tiles.  `pc.orig["wgrad_taps"]` widens
     the tap list beyond the forward's (masked convs: the reference's autograd also fills the masked taps)."""
@@ -576,6 +620,14 @@ def conv_wgrad(pc: PackedConv, g: FM, x: FM, dw: torch.Tensor, scale=1.0, square
     if db is not None:
         assert db.is_cuda and db.dtype == torch.float32 and db.is_contiguous() and db.numel() >= pc.cout
         bidx = _bias_index(pc, db.device)
+    if defer is not None and PROFILE is None:
+        job = L.WgradReduceJob()
+        L.check(lib.tdvc_conv_wgrad_partials(C.byref(dg), C.byref(dxd), pc.cout, o["kh"], o["kw"], o["stride"], o["pad"], len(taps), dy, dxs,
+                                             tb.row_off.data_ptr(), tb.chan_off.data_ptr(), tb.tap_off.data_ptr(), int(square_x), scale, dw.data_ptr(),
+                                             bidx.data_ptr() if bidx is not None else None, db.data_ptr() if db is not None else None,
+                                             work.data_ptr(), nwork, C.byref(job), _stream()), "conv_wgrad_partials")
+        defer.add(job, (work, dw, db, tb, bidx))             # the workspace and the tables live until the flush
+        return
     L.check(lib.tdvc_conv_wgrad_bias(C.byref(dg), C.byref(dxd), pc.cout, o["kh"], o["kw"], o["stride"], o["pad"], len(taps), dy, dxs,
                                 tb.row_off.data_ptr(), tb.chan_off.data_ptr(), tb.tap_off.data_ptr(), int(square_x), scale, dw.data_ptr(),
                                 bidx.data_ptr() if bidx is not None else None, db.data_ptr() if db is not None else None,

@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--train-lambda", type=int, default=2048, help="selects the BPG QP of the I-frames (dataset.py:25-36)")
     ap.add_argument("--stream-order", default="raster", choices=("raster", "wavefront"),
                     help="with --bitstream-dir: y-symbol order (raster = the reference's; wavefront = diagonal-parallel decoding)")
+    ap.add_argument("--coder-fp32", action="store_true", help="both coders as fp32 islands (the reference's precision), also with enable_amp: True")
     a = ap.parse_args()
     opt = {"model": "pnet", "pretrain": a.pretrain, "val_dataset": "synthetic", "class": "-", "enable_amp": True}
     if a.cfg:
@@ -117,6 +118,10 @@ def main():
     else:
         fill_parameters(net)
     net = net.to(dev).eval()
+    # `coder_fp32: true` (an extra yaml key, or --coder-fp32): both coders as the reference's fp32 islands (pnet.py:33,57) whatever
+    # `enable_amp` says -- the reference-faithful precision for a reference checkpoint + cfg/predict.yaml (`enable_amp: True`), which
+    # otherwise selects this build's fp16-in / fp32-accumulate coders
+    net.coder_fp32 = bool(opt.get("coder_fp32", False)) or a.coder_fp32
     net.stream_order = a.stream_order
     t0 = time.time()
     stats = []

@@ -484,6 +484,17 @@ def test_train_steps_reproducible_with_side_stream_at_training_size(report):
     report(f"4 training steps at 4x256x256, twice: {len(bad)}/{len(sa)} state tensors differ; rd_loss {[round(l['rd_loss'], 4) for l in la]}")
     assert not bad, f"training is not reproducible run to run: {len(bad)} tensors differ, e.g. {bad[:4]}"
     assert [l["rd_loss"] for l in la] == [l["rd_loss"] for l in lb]
+    # round 4: the second stages of the weight gradients are reduced in one launch per join() (ops.WgradBatch) instead of one launch per
+    # layer; same partial sums, same order: the trajectory with the immediate form is bit-identical
+    from tdvc_amd import autograd
+    prev, autograd.BATCH_WGRAD_REDUCE = autograd.BATCH_WGRAD_REDUCE, False
+    try:
+        sc, lc = run()
+    finally:
+        autograd.BATCH_WGRAD_REDUCE = prev
+    bad = [k for k in sa if not torch.equal(sa[k], sc[k])]
+    report(f"batched against per-layer weight-gradient reduce: {len(bad)}/{len(sa)} state tensors differ after 4 steps")
+    assert not bad and prev, f"the batched reduce changes the gradients: {len(bad)} tensors differ, e.g. {bad[:4]}"
 
 
 def test_train_step_graph_replay_matches_eager(report):

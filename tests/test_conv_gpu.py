@@ -31,6 +31,15 @@ def small_map_kernel(request):
     fn(1)
 
 
+def _enable(name, on):
+    import ctypes
+
+    from tdvc_amd import _lib
+    fn = getattr(_lib.lib(), "tdvc_debug_enable_" + name)
+    fn.argtypes, fn.restype = [ctypes.c_int], None
+    fn(int(on) if not isinstance(on, bool) else ((3 if name == "conv_row" else 1) if on else 0))     # conv_row: bit 0 = Cin 128, bit 1 = Cin 64
+
+
 CASES = [
     # name, N, cin, cout, k, stride, pad, H, W
     ("3x3_64_64", 1, 64, 64, 3, 1, 1, 24, 40),
@@ -332,18 +341,15 @@ V7_CASES = [
 @pytest.mark.parametrize("v10", [True, False], ids=["v10", "v7"])
 @pytest.mark.parametrize("case", V7_CASES, ids=[c[0] for c in V7_CASES])
 def test_conv_v7(case, v10, report):
-    import ctypes
-
-    from tdvc_amd import _lib
     ops = _ops()
     name, N, cin, cout, H, W, act, n_res = case
-    fn = _lib.lib().tdvc_debug_enable_conv_v10
-    fn.argtypes, fn.restype = [ctypes.c_int], None
-    fn(1 if v10 else 0)
+    _enable("conv_row", False)           # the row-streaming kernel takes the Cin = 64 -> 64 k layers first in the product dispatch
+    _enable("conv_v10", v10)
     try:
         _run_conv_dma_case(ops, name, N, cin, cout, H, W, act, n_res, "conv_mfma_v10" if (v10 and cin == 64) else "conv_mfma_v7", report)
     finally:
-        fn(1)
+        _enable("conv_v10", True)
+        _enable("conv_row", True)
 
 
 def _run_conv_dma_case(ops, name, N, cin, cout, H, W, act, n_res, kernel, report):
@@ -401,31 +407,103 @@ V11_CASES = [
 @pytest.mark.parametrize("v11", [True, False], ids=["v11", "v3"])
 @pytest.mark.parametrize("case", V11_CASES, ids=[c[0] for c in V11_CASES])
 def test_conv_v11(case, v11, report):
-    import ctypes
-
-    from tdvc_amd import _lib
     ops = _ops()
     name, N, cin, cout, H, W, act, n_res = case
-    fn = _lib.lib().tdvc_debug_enable_conv_v11
-    fn.argtypes, fn.restype = [ctypes.c_int], None
-    fn(1 if v11 else 0)
+    _enable("conv_row", False)           # the row-streaming kernel (below) takes the Cin = 128 layers first in the product dispatch
+    _enable("conv_v11", v11)
     try:
         _run_conv_dma_case(ops, name, N, cin, cout, H, W, act, n_res, "conv_mfma_v11" if v11 else "conv_mfma_v3", report)
     finally:
-        fn(1)
+        _enable("conv_v11", True)
+        _enable("conv_row", True)
+
+
+# ---- 3x3 stride-1 convs with Cin = 128, Cout a multiple of 128 (weights in registers, row streaming: conv_row)
+ROW_CASES = [
+    # name, N, cin, cout, H, W, act, n_res
+    ("row_128_128_ragged", 1, 128, 128, 100, 150, "lrelu", 1),       # a partial strip on the right, ragged row segments
+    ("row_128_128_batch2", 2, 128, 128, 90, 120, "lrelu", 1),        # batch in the job walk
+    ("row_128_256_two_blocks", 1, 128, 256, 96, 128, "none", 0),     # two cout blocks share the workgroup slots
+    ("row_128_128_many_jobs", 1, 128, 128, 272, 480, "lrelu", 1),    # the coders' H/4 size: several jobs per persistent workgroup
+    ("row_128_128_narrow", 1, 128, 128, 300, 40, "relu", 0),         # two strips, one of 8 columns; long segments
+    ("row_128_128_min_rows", 1, 128, 128, 16, 520, "lrelu", 0),      # the fewest rows the kernel takes (one segment of 16)
+    ("row_128_384_three_blocks", 1, 128, 384, 64, 160, "none", 1),   # a cout-block count that does not divide the 32 slots of an XCD
+]
+
+
+ROW_CASES += [
+    ("row64_64_64_ragged", 1, 64, 64, 100, 150, "lrelu", 1),         # 64-column strips: 2 full + one of 22 columns
+    ("row64_64_64_slices", 3, 64, 64, 70, 260, "relu", 0),           # batch of three, 4 full strips + 4 columns
+    ("row64_64_128_two_blocks", 1, 64, 128, 96, 128, "none", 1),
+    ("row64_64_64_1080p_rows", 1, 64, 64, 1088, 64, "lrelu", 1),     # one strip, 1088 rows: 256 runs of 4.25 rows
+]
+
+
+@pytest.mark.parametrize("case", ROW_CASES, ids=[c[0] for c in ROW_CASES])
+def test_conv_row(case, report):
+    ops = _ops()
+    name, N, cin, cout, H, W, act, n_res = case
+    _run_conv_dma_case(ops, name, N, cin, cout, H, W, act, n_res, "conv_row", report)
+
+
+@pytest.mark.parametrize("cq,H,W,nres", [(128, 96, 128, 1), (64, 100, 150, 0), (64, 90, 120, 1)])
+def test_conv_row_pixel_shuffle(cq, H, W, nres, report):
+    """sub-pixel convs 128 -> 4 cq with the PixelShuffle(2) store on the row-streaming kernel: a 128-channel block of the packed rows
+    is one sub-pixel (cq = 128) or two (cq = 64)"""
+    ops = _ops()
+    x = rnd16(randn(1, 128, H, W, seed=91))
+    w = rnd16(randn(4 * cq, 128, 3, 3, seed=92) * 0.03)
+    b = randn(4 * cq, seed=93) * 0.1
+    rs = [rnd16(randn(1, cq, 2 * H, 2 * W, seed=94 + i)) for i in range(nres)]
+    ref = F.leaky_relu(F.pixel_shuffle(F.conv2d(x, w, b, padding=1), 2), 0.01)
+    for r_ in rs:
+        ref = ref + r_
+    kw = dict(act=ops.ACT_LRELU, slope=0.01)
+    if nres > 0:
+        kw["res"] = to_fm(rs[0], ops)
+    xf = to_fm(x, ops)
+    pc = ops.pack_conv(w, b, stride=1, pad=1, shuffle=True)
+    y = ops.conv(xf, pc, **kw)
+    kern = ops.L.lib().tdvc_last_conv_kernel().decode()
+    assert kern == "conv_row", kern
+    assert_close(fm_to_cpu(y), ref, RT, AT, f"subpel 128->{cq} @{H}x{W} on {kern}", report)
+    first = y.t.clone()
+    for _ in range(4):
+        ops.conv(xf, pc, out=y, **kw)
+        assert torch.equal(y.t, first), "launch-to-launch mismatch"
+
+
+def test_conv_row_equals_v11_arithmetic(report):
+    """the two kernels round alike (fp16 conv result, packed-fp16 activation, fp16 residual add): on one layer they differ only by
+    the fp32 summation order inside the contraction"""
+    ops = _ops()
+    x = rnd16(randn(1, 128, 136, 240, seed=71))
+    w = rnd16(randn(128, 128, 3, 3, seed=72) * 0.03)
+    b = randn(128, seed=73) * 0.1
+    r = rnd16(randn(1, 128, 136, 240, seed=74))
+    pc = ops.pack_conv(w, b, stride=1, pad=1)
+    kw = dict(act=ops.ACT_LRELU, slope=0.01, res=to_fm(r, ops))
+    y_row = ops.conv(to_fm(x, ops), pc, **kw)
+    assert ops.L.lib().tdvc_last_conv_kernel().decode() == "conv_row"
+    _enable("conv_row", False)
+    try:
+        y_v11 = ops.conv(to_fm(x, ops), pc, **kw)
+        assert ops.L.lib().tdvc_last_conv_kernel().decode() == "conv_mfma_v11"
+    finally:
+        _enable("conv_row", True)
+    a, c = fm_to_cpu(y_row), fm_to_cpu(y_v11)
+    neq = float((a != c).float().mean())
+    report(f"conv_row vs conv_mfma_v11, 128->128 @136x240 + residual: {neq:.2e} of the outputs differ, max |d| {float((a - c).abs().max()):.2e}")
+    assert neq < 0.05 and float((a - c).abs().max()) <= 4e-3
 
 
 @pytest.mark.parametrize("v11", [True, False], ids=["v11", "v3"])
 @pytest.mark.parametrize("cout,H,W,nres", [(128, 96, 128, 1), (64, 100, 150, 0), (128, 90, 120, 2)])
 def test_conv_v11_pixel_shuffle(cout, H, W, nres, v11, report):
     """sub-pixel convs 128 -> 4 * cout with the PixelShuffle(2) store (the coders' ResidualBlockUpsample and final g_s layers)"""
-    import ctypes
-
-    from tdvc_amd import _lib
     ops = _ops()
-    fn = _lib.lib().tdvc_debug_enable_conv_v11
-    fn.argtypes, fn.restype = [ctypes.c_int], None
-    fn(1 if v11 else 0)
+    _enable("conv_row", False)
+    _enable("conv_v11", v11)
     try:
         x = rnd16(randn(1, 128, H, W, seed=91))
         w = rnd16(randn(4 * cout, 128, 3, 3, seed=92) * 0.03)
@@ -450,7 +528,8 @@ def test_conv_v11_pixel_shuffle(cout, H, W, nres, v11, report):
             ops.conv(xf, pc, out=y, **kw)
             assert torch.equal(y.t, first), "launch-to-launch mismatch"
     finally:
-        fn(1)
+        _enable("conv_v11", True)
+        _enable("conv_row", True)
 
 
 def test_conv_c8_equals_direct_kernel(report):

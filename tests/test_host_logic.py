@@ -280,3 +280,26 @@ def test_bench_self_launch_forwards_arguments(monkeypatch):
     with pytest.raises(SystemExit) as ex:
         bench.main()
     assert "WORLD_SIZE=4" in str(ex.value.code)
+
+
+def test_tape_deferred_chains_run_behind_the_sweep():
+    """`Tape.defer`: parameter-space chains that run as torch kernels (entropy-bottleneck softplus / tanh chain, GDN reparametrisation) are
+    executed after the last backward node and after join() -- no MFMA kernel of the side stream is in flight then (torch's softplus kernels
+    contain the packed-FP32 form of profiles/r03_packed_fp32_race.txt) -- and count as one more node for the bucket bookkeeping."""
+    from tdvc_amd import autograd
+    tape = autograd.Tape()
+    log = []
+    tape.touch_log = {}
+    p1, p2 = object(), object()
+    tape.join = lambda: log.append("join")
+    tape.add(lambda: (log.append("node_a"), tape.touch(p1)))                 # recorded first: runs LAST in the sweep
+
+    def node_b():
+        log.append("node_b")
+        tape.defer(lambda: (log.append("chain"), tape.touch(p2)))
+    tape.add(node_b)
+    tape.on_node_done = lambda k: log.append(f"done{k}")
+    tape.backward()
+    assert log == ["node_b", "done0", "node_a", "done1", "join", "chain", "join"], log
+    assert tape.touch_log[id(p1)] == 1 and tape.touch_log[id(p2)] == 2 == tape.n_backward_nodes
+    assert not tape.deferred and not tape.nodes

@@ -238,9 +238,13 @@ def test_forward_fp32_islands(models, H, W, report):
     assert s32["mv.y_hat_flips"] <= s16["mv.y_hat_flips"] + 1e-4 and s32["mv.y"] <= s16["mv.y"]
 
 
+SWA_ITERS = 100
+
+
 def _train_to_operating_point(report, max_iters=600, target_bpp=0.30, lam=256.0):
     """deterministic TrainSteps on synthetic septuplets (batch 4, 256x256, the tools/train.py sample rule) from the filler
-    initialisation until the training-mode rate is under `target_bpp`; -> (model in eval mode, log of the last step)"""
+    initialisation until the training-mode rate is under `target_bpp` (or `max_iters`), then SWA_ITERS more whose iterates are
+    averaged; -> (model in eval mode holding the LAST iterate, rate ema, state-dict of the averaged iterates)"""
     from tdvc_amd.model import VideoCompressor
     from tdvc_amd.synth import fill_parameters, make_gop, ref_list
     from tdvc_amd import ops
@@ -253,7 +257,8 @@ def _train_to_operating_point(report, max_iters=600, target_bpp=0.30, lam=256.0)
         net = net.cuda().train()
         step = TrainStep(net, train_lambda=lam, lr=2e-4, loss_scale=128.0)
         pool, cursor, ema, log = [], 0, None, None
-        for it in range(max_iters):
+        swa, swa_left = None, None
+        for it in range(max_iters + SWA_ITERS):
             while len(pool) < 4:
                 gop = make_gop(5000 + cursor, 7, 256, 256)
                 cursor += 1
@@ -267,8 +272,14 @@ def _train_to_operating_point(report, max_iters=600, target_bpp=0.30, lam=256.0)
             ema = bpp if ema is None else 0.9 * ema + 0.1 * bpp
             if (it + 1) % 50 == 0:
                 report(f"   train-to-operating-point it {it + 1}: rd_loss {log['rd_loss']:.4f} bpp {bpp:.4f} (ema {ema:.4f}) mse {log['mse']:.2e}")
-            if it >= 100 and ema <= target_bpp:
-                break
+            if swa_left is None and ((it >= 100 and ema <= target_bpp) or it + 1 >= max_iters):
+                swa_left = SWA_ITERS                          # the operating point is reached: average the next SWA_ITERS iterates
+            elif swa_left is not None:
+                sd_ = {k: v.detach().double() for k, v in net.state_dict().items() if v.dtype.is_floating_point}
+                swa = {k: v.clone() for k, v in sd_.items()} if swa is None else {k: swa[k] + sd_[k] for k in sd_}
+                swa_left -= 1
+                if swa_left == 0:
+                    break
     finally:
         ops.DETERMINISTIC = prev_det                         # an exception during training must not leave the global on for later tests
     import hashlib
@@ -277,7 +288,8 @@ def _train_to_operating_point(report, max_iters=600, target_bpp=0.30, lam=256.0)
         hsh.update(k.encode()); hsh.update(v.detach().cpu().contiguous().numpy().tobytes())
     report(f"   trained {it + 1} iterations (lambda {lam:g}): training-mode bpp ema {ema:.4f}; state-dict sha256 {hsh.hexdigest()[:16]} "
            f"(deterministic TrainSteps from seed 1111: the same digest on every run of this build)")
-    return net.eval(), ema
+    swa_sd = {k: ((swa[k] / SWA_ITERS).float().cpu() if k in swa else v.detach().cpu().clone()) for k, v in net.state_dict().items()}
+    return net.eval(), ema, swa_sd
 
 
 def _fp16_exact(sd):
@@ -290,33 +302,50 @@ def _fp16_exact(sd):
     return out
 
 
+class _Trained:
+    pass
+
+
 @pytest.fixture(scope="module")
 def trained(report):
-    """(HIP model, fp32 CPU oracle, HIP model with the raw master weights) at the trained operating point, built once per module run.
+    """Models at a trained operating point, built once per module run (deterministic training: the same weights every run).
 
-    The checkpoint both paths load is FP16-EXACT in its conv weights (`_fp16_exact`).  Reason (measured, r03): TrainStep
-    optimises the loss of the network the HIP path evaluates, i.e. of the fp16-ROUNDED weights; the fp32 master weights
-    differ from them by the rounding residual, one fixed perturbation of the whole network, and the fp32 oracle loaded
-    with the master weights coded every frame 0.020-0.035 dB WORSE than the HIP path (same sign on all 8 frames and in both
-    coder modes, 1088x1920: +0.0315 dB; |dbpp| 1.5e-4) -- a statement about checkpoint precision, not about kernel
-    arithmetic.  With an fp16-exact checkpoint the two paths evaluate the same function and the north_star gates test what
-    they are meant to test; the master-weight effect is reported by test_trained_master_weights_effect."""
+    `last`: the LAST training iterate.  Round 3 found the fp32 oracle on its raw fp32 master weights 0.02-0.035 dB below the HIP
+    path, one sign on all frames; round 4 measured why (tools/parity_diag.py): the last iterate of a constant
+    learning-rate run is HYPERSENSITIVE -- the HIP path itself loses 0.008-0.031 dB when every conv weight is multiplied by
+    (1 + 2^-12 xi) (half an fp16 ulp, a second independent "rounding"), and on it the reference's own two paths (fp32 CPU
+    restatement / AMP emulation) differ by 0.04 dB, twice the north_star gate.  No arithmetic can sit within 0.02 dB of both.
+    `net` / `ref` keep round 3's statement on that iterate: an fp16-EXACT copy of it (`_fp16_exact`) on the HIP path and on the
+    fp32 oracle, i.e. one function evaluated by two arithmetics.
+
+    `swa_*`: the mean of SWA_ITERS further iterates (stochastic weight averaging: what a converged, learning-rate-decayed run
+    ends on), as a RAW fp32 checkpoint -- not fp16-exact, the form a user's checkpoint has -- on the HIP path, on the oracle in
+    AMP emulation (`amp_emulation = True`: what the reference computes on a GPU with `enable_amp: True`, fp16 convs in the
+    three autocast regions around fp32 coders) and on the fp32 oracle.  On it the perturbation costs the HIP path < 0.005 dB and
+    all paths agree: this is the checkpoint the north_star gates are asserted on."""
     from oracle.tdvc_ref import VideoCompressor as Ref
     from tdvc_amd.model import VideoCompressor
-    raw, ema = _train_to_operating_point(report)
-    sd_raw = {k: v.detach().cpu() for k, v in raw.state_dict().items()}
-    sd = _fp16_exact(sd_raw)
-    net = VideoCompressor()
-    net.load_state_dict(sd, strict=True)
-    net = net.cuda().eval()
-    ref = Ref().eval()
-    ref.load_state_dict(sd, strict=True)
-    # the RAW fp32 master weights (what a user's checkpoint holds) on the AMP-emulating oracle: what the reference computes on a
-    # GPU with `enable_amp: True` (fp16 convs in the three autocast regions around fp32 coders, oracle/tdvc_ref/codec.py)
-    ref_amp = Ref().eval()
-    ref_amp.load_state_dict(sd_raw, strict=True)
-    ref_amp.amp_emulation = True
-    return net, ref, raw, ref_amp
+
+    def hip(sd):
+        m = VideoCompressor()
+        m.load_state_dict(sd, strict=True)
+        return m.cuda().eval()
+
+    def oracle(sd, amp):
+        r = Ref().eval()
+        r.load_state_dict(sd, strict=True)
+        r.amp_emulation = amp
+        return r
+
+    T = _Trained()
+    T.last, ema, swa_sd = _train_to_operating_point(report)
+    T.last_sd = {k: v.detach().cpu() for k, v in T.last.state_dict().items()}
+    sd = _fp16_exact(T.last_sd)
+    T.net, T.ref = hip(sd), oracle(sd, False)
+    T.last_amp = oracle(T.last_sd, True)
+    T.swa_sd = swa_sd
+    T.swa_hip, T.swa_amp, T.swa_fp32 = hip(swa_sd), oracle(swa_sd, True), oracle(swa_sd, False)
+    return T
 
 
 def test_trained_master_weights_effect(trained, report):
@@ -327,7 +356,7 @@ def test_trained_master_weights_effect(trained, report):
     any kernel arithmetic enters."""
     from oracle.tdvc_ref import VideoCompressor as Ref
     from tdvc_amd.synth import make_gop, ref_list
-    net, ref, raw, _ = trained
+    net, ref, raw = trained.net, trained.ref, trained.last
     ref_raw = Ref().eval()
     ref_raw.load_state_dict({k: v.detach().cpu() for k, v in raw.state_dict().items()}, strict=True)
     g = make_gop(1234, 3, 256, 256)
@@ -356,7 +385,7 @@ def test_trained_operating_point_parity(trained, report):
     the PSNR gate holds for the median with three times the gate on every single frame, the rate as a distribution over 18
     frames (below), next to the direct statement that the two reconstructions agree to > 65 dB."""
     from tdvc_amd.synth import make_gop, ref_list
-    net, ref, _, _ = trained
+    net, ref = trained.net, trained.ref
     worst, d256, dps = 0.0, [], []
     for (H, W, seeds) in ((256, 256, (1234, 1235, 1236)), (512, 768, (1234,))):
         big = H * W >= 512 * 768
@@ -380,7 +409,7 @@ def test_trained_operating_point_parity(trained, report):
                 # model): at 33-36 dB a deviation of 8e-5 RMS can move the PSNR by up to 0.04 dB, measured 0.002-0.022 dB
                 agree16, agree32 = psnr(r16.cpu(), ro), psnr(r32.cpu(), ro)
                 assert agree16 >= 65.0 and agree32 >= 65.0, f"reconstructions differ: PSNR(gpu, oracle) {agree16:.1f} / {agree32:.1f} dB"
-                gate_p = 0.02 if big else 0.06
+                gate_p = 0.02                            # r03: 0.06 at 256x256; measured 0.0013-0.0057 dB on the fp16-exact checkpoint
                 assert abs(p_16 - p_o) <= gate_p and abs(p_32 - p_o) <= gate_p, f"a {H}x{W} frame misses the {gate_p} dB PSNR bound"
                 assert abs(d32) <= (1e-3 if big else 3e-3), "fp32-island mode misses the rate bound at the trained operating point"
                 if big:
@@ -420,7 +449,7 @@ def test_trained_operating_point_parity_1080p(trained, report):
     import time
     import torch.nn.functional as F
     from tdvc_amd.synth import make_gop, ref_list
-    net, ref, _, _ = trained
+    net, ref = trained.net, trained.ref
     g = F.pad(make_gop(1234, 2, 1080, 1920), (0, 0, 4, 4))
     refs = ref_list([g[0:1]])
     torch.set_num_threads(min(16, torch.get_num_threads()))
@@ -449,14 +478,31 @@ def _code_frame(model, x, refs, amp):
     return r, float(br + bm)
 
 
+def _within_reference_spread(d_hip_amp, d_f32_amp, gate):
+    """the criterion against the AMP-emulating oracle: inside the gate -- or, where the reference's OWN two paths (fp32 CPU / AMP
+    emulation) are further apart than half the gate, no further from the AMP path than the reference's CPU path is, plus half the gate"""
+    return abs(d_hip_amp) <= max(gate, abs(d_f32_amp) + 0.5 * gate)
+
+
+def _idx_note(tr, amp, f32):
+    i_h = tr["ff_idx"].cpu().long()
+    i_a, i_f = amp.loopfilter.last_match_index, f32.loopfilter.last_match_index
+    return f"patch indices hip/fp32 {int((i_h != i_f).sum())} hip/amp {int((i_h != i_a).sum())} fp32/amp {int((i_f != i_a).sum())} of {i_h.numel()} differ"
+
+
 def test_trained_raw_checkpoint_parity_amp_oracle(trained, report):
-    """RAW fp32 master weights, no `_fp16_exact`: the HIP path against the oracle in AMP emulation (`amp_emulation = True`: the
-    function the reference evaluates on a GPU with `enable_amp: True`, pnet.py:27-78 -- fp16 convs around fp32 coders).  Per
-    frame, open loop (both paths code from the oracle's reference list), 256x256 (reported; PSNR gate 0.02 on the median) and
-    512x768 (gated per frame): fp32-island mode |dPSNR| <= 0.02 dB, |dbpp| <= 0.001; the default mode (fp16 coder weights,
-    which the reference does not have) is measured against the same gates and its numbers are what `bench.py` reports."""
+    """RAW fp32 weights, no `_fp16_exact`: the averaged checkpoint (fixture) on the HIP path against BOTH paths of the reference:
+    the fp32 oracle (its CPU path, the one north_star names) and the oracle in AMP emulation (`amp_emulation = True`: what it
+    computes on a GPU with `enable_amp: True`, pnet.py:27-78 -- fp16 convs around fp32 coders).  Per frame, open loop (all paths
+    code from the fp32 oracle's reference list), 256x256 and 512x768.
+    Against the fp32 oracle: the north_star gates themselves, |dPSNR| <= 0.02 dB and |dbpp| <= 0.001, in the fp32-island mode AND
+    in the default mode (fp16 coder weights, which the reference does not have); 0.003 bpp at 256x256, where one flipped motion
+    symbol is 1-2.4e-3 bpp of a 65 k-pixel frame.
+    Against the AMP emulation: the same gates wherever the reference's own two paths agree with each other; they do not always
+    (r04: 0.027 dB apart on the 512x768 frame at 38 dB, where the HIP path sat 0.006 dB from the fp32 path and 0.0215 dB from
+    the AMP path), and no implementation can be within 0.02 dB of both then: `_within_reference_spread`."""
     from tdvc_amd.synth import make_gop, ref_list
-    _, _, raw, ref_amp = trained
+    hip, amp, f32 = trained.swa_hip, trained.swa_amp, trained.swa_fp32
     rows = []
     for (H, W, seeds) in ((256, 256, (1234, 1235)), (512, 768, (1234,))):
         big = H * W >= 512 * 768
@@ -465,77 +511,141 @@ def test_trained_raw_checkpoint_parity_amp_oracle(trained, report):
             refs_l = [g[0:1]]
             for t in (1, 2):
                 refs = ref_list(refs_l)
-                ro, bo = _code_frame(ref_amp, g[t:t + 1], refs, True)
-                r16, b16 = _code_frame(raw, g[t:t + 1].cuda(), refs.cuda(), True)
-                r32, b32 = _code_frame(raw, g[t:t + 1].cuda(), refs.cuda(), False)
-                p_o, p_16, p_32 = psnr(ro, g[t:t + 1]), psnr(r16.cpu(), g[t:t + 1]), psnr(r32.cpu(), g[t:t + 1])
-                report(f"[raw checkpoint vs AMP oracle, {H}x{W} seed {seed} frame {t}] oracle {bo:.5f} bpp {p_o:.4f} dB | fp32 islands dbpp {b32 - bo:+.5f} "
-                       f"dPSNR {p_32 - p_o:+.4f} | default mode dbpp {b16 - bo:+.5f} dPSNR {p_16 - p_o:+.4f} | PSNR(gpu, oracle) {psnr(r32.cpu(), ro):.1f} / {psnr(r16.cpu(), ro):.1f} dB")
-                rows.append((big, p_32 - p_o, b32 - bo, p_16 - p_o, b16 - bo))
-                if big:
-                    assert abs(p_32 - p_o) <= 0.02 and abs(b32 - bo) <= 1e-3, "fp32-island mode misses the north_star gates on a raw checkpoint"
-                    assert abs(p_16 - p_o) <= 0.02 and abs(b16 - bo) <= 1e-3, "default mode misses the north_star gates on a raw checkpoint"
-                refs_l.append(ro)
-    med = lambda vals: sorted(vals)[len(vals) // 2]
-    small = [r for r in rows if not r[0]]
-    report(f"[raw checkpoint vs AMP oracle, 256x256, {len(small)} frames] median |dPSNR| islands {med([abs(r[1]) for r in small]):.4f} default "
-           f"{med([abs(r[3]) for r in small]):.4f}; max |dPSNR| {max(abs(r[1]) for r in small):.4f} / {max(abs(r[3]) for r in small):.4f}; "
-           f"max |dbpp| {max(abs(r[2]) for r in small):.5f} / {max(abs(r[4]) for r in small):.5f}")
-    assert med([abs(r[1]) for r in small]) <= 0.02 and med([abs(r[3]) for r in small]) <= 0.02
-    assert max(abs(r[1]) for r in small) <= 0.04 and max(abs(r[3]) for r in small) <= 0.04
-    assert max(abs(r[2]) for r in small) <= 3e-3
+                ro, bo = _code_frame(amp, g[t:t + 1], refs, True)
+                rf, bf = _code_frame(f32, g[t:t + 1], refs, False)
+                tr = {}
+                with torch.no_grad():
+                    r16, br16, bm16 = hip(g[t:t + 1].cuda(), refs.cuda(), True, trace=tr)
+                b16 = float(br16 + bm16)
+                r32, b32 = _code_frame(hip, g[t:t + 1].cuda(), refs.cuda(), False)
+                p_o, p_f, p_16, p_32 = psnr(ro, g[t:t + 1]), psnr(rf, g[t:t + 1]), psnr(r16.cpu(), g[t:t + 1]), psnr(r32.cpu(), g[t:t + 1])
+                report(f"[raw averaged checkpoint, {H}x{W} seed {seed} frame {t}] fp32 oracle {bf:.5f} bpp {p_f:.4f} dB | fp32 islands dbpp {b32 - bf:+.5f} dPSNR {p_32 - p_f:+.4f} | "
+                       f"default mode dbpp {b16 - bf:+.5f} dPSNR {p_16 - p_f:+.4f} | AMP oracle against the fp32 oracle dbpp {bo - bf:+.5f} dPSNR {p_o - p_f:+.4f}; "
+                       f"HIP against the AMP oracle dPSNR {p_32 - p_o:+.4f} / {p_16 - p_o:+.4f} | PSNR(gpu, fp32 oracle) {psnr(r32.cpu(), rf):.1f} / {psnr(r16.cpu(), rf):.1f} dB, "
+                       f"PSNR(gpu, AMP oracle) {psnr(r32.cpu(), ro):.1f} dB, PSNR(fp32, AMP oracle) {psnr(rf, ro):.1f} dB | {_idx_note(tr, amp, f32)}")
+                assert bf < 1.2, "not a trained-like operating point"
+                gate_b = 1e-3 if big else 3e-3
+                assert abs(p_32 - p_f) <= 0.02 and abs(b32 - bf) <= gate_b, "fp32-island mode misses the north_star gates against the fp32 CPU oracle on a raw checkpoint"
+                assert abs(p_16 - p_f) <= 0.02 and abs(b16 - bf) <= gate_b, "default mode misses the north_star gates against the fp32 CPU oracle on a raw checkpoint"
+                assert _within_reference_spread(p_32 - p_o, p_f - p_o, 0.02) and _within_reference_spread(p_16 - p_o, p_f - p_o, 0.02), \
+                    "the HIP path is further from the AMP emulation than the reference's own CPU path is"
+                assert abs(b32 - bo) <= gate_b and abs(b16 - bo) <= gate_b, "rate gate against the AMP emulation"
+                rows.append((abs(p_32 - p_f), abs(p_16 - p_f), abs(p_32 - p_o), abs(p_f - p_o)))
+                refs_l.append(rf)
+    report(f"[raw averaged checkpoint, {len(rows)} frames] max |dPSNR| against the fp32 oracle: islands {max(r[0] for r in rows):.4f}, default {max(r[1] for r in rows):.4f}; "
+           f"against the AMP oracle {max(r[2] for r in rows):.4f}; the reference's own two paths (fp32 oracle against AMP oracle) {max(r[3] for r in rows):.4f} dB")
 
 
 def test_trained_raw_checkpoint_parity_amp_oracle_1080p(trained, report):
-    """the same statement at the headline size: one cfg-2 P-frame at 1088x1920, raw master weights, HIP path (both coder modes)
-    against the AMP-emulating oracle; the north_star gates themselves."""
+    """the same statement at the headline size: one cfg-2 P-frame at 1088x1920, raw averaged checkpoint, HIP path (both coder
+    modes) against the AMP-emulating oracle; the north_star gates themselves, patch-match indices bit-equal.  (The fp32 oracle
+    at this size: test_trained_operating_point_parity_1080p, on the fp16-exact last iterate.)"""
     import time
     import torch.nn.functional as F
     from tdvc_amd.synth import make_gop, ref_list
-    _, _, raw, ref_amp = trained
+    hip, amp = trained.swa_hip, trained.swa_amp
     g = F.pad(make_gop(1234, 2, 1080, 1920), (0, 0, 4, 4))
     refs = ref_list([g[0:1]])
     torch.set_num_threads(min(16, torch.get_num_threads()))
     t0 = time.time()
-    ro, bo = _code_frame(ref_amp, g[1:2], refs, True)
+    ro, bo = _code_frame(amp, g[1:2], refs, True)
     t_cpu = time.time() - t0
     tr16 = {}
     with torch.no_grad():
-        r16, br16, bm16 = raw(g[1:2].cuda(), refs.cuda(), True, trace=tr16)
+        r16, br16, bm16 = hip(g[1:2].cuda(), refs.cuda(), True, trace=tr16)
     b16 = float(br16 + bm16)
-    r32, b32 = _code_frame(raw, g[1:2].cuda(), refs.cuda(), False)
+    r32, b32 = _code_frame(hip, g[1:2].cuda(), refs.cuda(), False)
     crop = lambda t: t[:, :, 4:-4]
     p_o, p_16, p_32 = psnr(crop(ro), crop(g[1:2])), psnr(crop(r16.cpu()), crop(g[1:2])), psnr(crop(r32.cpu()), crop(g[1:2]))
-    report(f"[raw checkpoint vs AMP oracle, 1088x1920] oracle {t_cpu:.1f} s | oracle {bo:.5f} bpp {p_o:.4f} dB | fp32 islands dbpp {b32 - bo:+.6f} dPSNR {p_32 - p_o:+.5f} | "
+    report(f"[raw averaged checkpoint vs AMP oracle, 1088x1920] oracle {t_cpu:.1f} s | oracle {bo:.5f} bpp {p_o:.4f} dB | fp32 islands dbpp {b32 - bo:+.6f} dPSNR {p_32 - p_o:+.5f} | "
            f"default mode dbpp {b16 - bo:+.6f} dPSNR {p_16 - p_o:+.5f} | PSNR(gpu, oracle) {psnr(r32.cpu(), ro):.1f} / {psnr(r16.cpu(), ro):.1f} dB")
-    assert bo < 1.0
-    assert torch.equal(tr16["ff_idx"].cpu().long(), ref_amp.loopfilter.last_match_index), "in-loop filter patch argmax differs"
+    assert bo < 1.2
+    assert torch.equal(tr16["ff_idx"].cpu().long(), amp.loopfilter.last_match_index), "in-loop filter patch argmax differs"
     assert abs(p_32 - p_o) <= 0.02 and abs(b32 - bo) <= 1e-3, "fp32-island mode misses the north_star gates at 1088x1920 on a raw checkpoint"
     assert abs(p_16 - p_o) <= 0.02 and abs(b16 - bo) <= 1e-3, "default mode misses the north_star gates at 1088x1920 on a raw checkpoint"
 
 
 def test_trained_closed_loop_gop(trained, report):
-    """BASELINE's metric is a GOP-level PSNR / BPP delta: one closed-loop GOP of 6 P-frames at 512x768 with the trained raw
-    weights, EACH path continuing from its own reconstructions (the reference-list rule of tools/predict.py:55-68): the
-    AMP-emulating oracle, the HIP path with fp32 islands and in the default mode.  Gates on the GOP means: |dPSNR| <= 0.02 dB,
-    |dbpp| <= 0.001; the per-frame drift is reported."""
+    """BASELINE's metric is a GOP-level PSNR / BPP delta: one closed-loop GOP of 6 P-frames at 512x768 with the raw averaged
+    checkpoint, EACH path continuing from its own reconstructions (the reference-list rule of tools/predict.py:55-68): the fp32
+    oracle, the AMP-emulating oracle, the HIP path with fp32 islands and in the default mode.  Gates on the GOP means against
+    the fp32 oracle: |dPSNR| <= 0.02 dB, |dbpp| <= 0.001; against the AMP emulation `_within_reference_spread`; the per-frame
+    drift is reported and bounded at twice the gate (against the fp32 oracle)."""
     from tdvc_amd.synth import make_gop, ref_list
-    _, _, raw, ref_amp = trained
+    hip, amp, f32 = trained.swa_hip, trained.swa_amp, trained.swa_fp32
     g = make_gop(1234, 7, 512, 768)
-    lists = {"oracle": [g[0:1]], "islands": [g[0:1].cuda()], "default": [g[0:1].cuda()]}
+    lists = {"fp32": [g[0:1]], "amp": [g[0:1]], "islands": [g[0:1].cuda()], "default": [g[0:1].cuda()]}
     acc = {k: [] for k in lists}
     for t in range(1, 7):
         x = g[t:t + 1]
-        ro, bo = _code_frame(ref_amp, x, ref_list(lists["oracle"]), True)
-        r32, b32 = _code_frame(raw, x.cuda(), ref_list(lists["islands"]), False)
-        r16, b16 = _code_frame(raw, x.cuda(), ref_list(lists["default"]), True)
-        for k, r, b in (("oracle", ro, bo), ("islands", r32, b32), ("default", r16, b16)):
+        rf, bf = _code_frame(f32, x, ref_list(lists["fp32"]), False)
+        ro, bo = _code_frame(amp, x, ref_list(lists["amp"]), True)
+        tr = {}
+        with torch.no_grad():
+            r32, br32, bm32 = hip(x.cuda(), ref_list(lists["islands"]), False, trace=tr)
+        b32 = float(br32 + bm32)
+        r16, b16 = _code_frame(hip, x.cuda(), ref_list(lists["default"]), True)
+        for k, r, b in (("fp32", rf, bf), ("amp", ro, bo), ("islands", r32, b32), ("default", r16, b16)):
             acc[k].append((psnr(r.cpu(), x), b))
             lists[k].append(r)
-        report(f"[closed-loop GOP 512x768 frame {t}] oracle {bo:.5f} bpp {acc['oracle'][-1][0]:.4f} dB | fp32 islands dbpp {b32 - bo:+.5f} dPSNR "
-               f"{acc['islands'][-1][0] - acc['oracle'][-1][0]:+.4f} | default dbpp {b16 - bo:+.5f} dPSNR {acc['default'][-1][0] - acc['oracle'][-1][0]:+.4f}")
+        pf = acc["fp32"][-1][0]
+        report(f"[closed-loop GOP 512x768 frame {t}] fp32 oracle {bf:.5f} bpp {pf:.4f} dB | fp32 islands dbpp {b32 - bf:+.5f} dPSNR {acc['islands'][-1][0] - pf:+.4f} | "
+               f"default dbpp {b16 - bf:+.5f} dPSNR {acc['default'][-1][0] - pf:+.4f} | AMP oracle dbpp {bo - bf:+.5f} dPSNR {acc['amp'][-1][0] - pf:+.4f} | {_idx_note(tr, amp, f32)}")
+        for k in ("islands", "default"):
+            assert abs(acc[k][-1][0] - pf) <= 0.04 and abs(acc[k][-1][1] - bf) <= 2e-3, f"{k}: frame {t} drifts past twice the gate"
     mean = lambda k, i: sum(v[i] for v in acc[k]) / len(acc[k])
+    da = mean("fp32", 0) - mean("amp", 0)
+    report(f"[closed-loop GOP 512x768, 6 P-frames] the reference's own two paths: fp32 oracle {mean('fp32', 0):.4f} dB {mean('fp32', 1):.5f} bpp, AMP emulation "
+           f"{mean('amp', 0):.4f} dB {mean('amp', 1):.5f} bpp (fp32 - AMP {da:+.4f} dB)")
     for k in ("islands", "default"):
-        dp, db = mean(k, 0) - mean("oracle", 0), mean(k, 1) - mean("oracle", 1)
-        report(f"[closed-loop GOP 512x768, 6 P-frames] {k}: GOP-mean dPSNR {dp:+.4f} dB, dbpp {db:+.5f} (oracle {mean('oracle', 0):.4f} dB, {mean('oracle', 1):.5f} bpp)")
-        assert abs(dp) <= 0.02 and abs(db) <= 1e-3, f"{k}: closed-loop GOP means miss the north_star gates"
+        dp, db = mean(k, 0) - mean("fp32", 0), mean(k, 1) - mean("fp32", 1)
+        dpa, dba = mean(k, 0) - mean("amp", 0), mean(k, 1) - mean("amp", 1)
+        report(f"[closed-loop GOP 512x768, 6 P-frames] {k}: GOP-mean dPSNR {dp:+.4f} dB, dbpp {db:+.5f} against the fp32 oracle; {dpa:+.4f} dB, {dba:+.5f} against the AMP emulation")
+        assert abs(dp) <= 0.02 and abs(db) <= 1e-3, f"{k}: closed-loop GOP means miss the north_star gates against the fp32 CPU oracle"
+        assert _within_reference_spread(dpa, da, 0.02) and abs(dba) <= 1e-3, f"{k}: closed-loop GOP means further from the AMP emulation than the reference's own CPU path"
+
+
+def _perturbed(sd, eps, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {k: (v * (1.0 + eps * (2.0 * torch.rand(v.shape, generator=g) - 1.0)) if (v.dtype.is_floating_point and k.endswith(".weight") and v.dim() >= 4) else v.clone())
+            for k, v in sd.items()}
+
+
+def test_last_iterate_sensitivity(trained, report):
+    """why the gates are asserted on the averaged checkpoint (r03 left this "inferred, not isolated"): the sensitivity of a
+    checkpoint to half an fp16 ulp.  Every conv weight is multiplied by (1 + 2^-12 xi), xi uniform in [-1, 1) -- what ANY
+    fp16-weight evaluation, the reference's own autocast included, does to a raw checkpoint -- and the HIP path (fp32 islands)
+    codes the same frames with both.  Last iterate: measured -0.008 ... -0.031 dB, one sign, and the reference's own two paths
+    (fp32 / AMP emulation) 0.04 dB apart on it: a statement about that checkpoint, not about anybody's kernels.  Averaged
+    checkpoint: under 0.005 dB.  Asserted: the averaged checkpoint is at least as insensitive as the gate needs (< 0.01 dB)."""
+    from tdvc_amd.model import VideoCompressor
+    from tdvc_amd.synth import make_gop, ref_list
+
+    def hip(sd):
+        m = VideoCompressor()
+        m.load_state_dict(sd, strict=True)
+        return m.cuda().eval()
+
+    out = {}
+    for name, sd, base in (("last iterate", trained.last_sd, trained.last), ("averaged", trained.swa_sd, trained.swa_hip)):
+        ds = []
+        for seed_p in (1, 2):
+            pert = hip(_perturbed(sd, 2.0 ** -12, seed_p))
+            for seed in (1234, 1235):
+                g = make_gop(seed, 2, 256, 256)
+                x, refs = g[1:2].cuda(), ref_list([g[0:1]]).cuda()
+                r0, _ = _code_frame(base, x, refs, False)
+                r1, _ = _code_frame(pert, x, refs, False)
+                ds.append(psnr(r1.cpu(), g[1:2]) - psnr(r0.cpu(), g[1:2]))
+            del pert
+        out[name] = ds
+        report(f"[sensitivity to w * (1 + 2^-12 xi), HIP path, 256x256] {name}: dPSNR " + " ".join(f"{d:+.4f}" for d in ds))
+    g = make_gop(1234, 2, 256, 256)
+    refs = ref_list([g[0:1]])
+    ra, _ = _code_frame(trained.last_amp, g[1:2], refs, True)
+    last_f32 = type(trained.swa_fp32)().eval()
+    last_f32.load_state_dict(trained.last_sd, strict=True)
+    rf, _ = _code_frame(last_f32, g[1:2], refs, False)
+    report(f"[last iterate, 256x256] the reference's own two paths: AMP emulation {psnr(ra, g[1:2]):.4f} dB, fp32 {psnr(rf, g[1:2]):.4f} dB ({psnr(ra, g[1:2]) - psnr(rf, g[1:2]):+.4f})")
+    assert max(abs(d) for d in out["averaged"]) < 0.01
+    assert max(abs(d) for d in out["last iterate"]) < 0.1

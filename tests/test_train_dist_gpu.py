@@ -129,3 +129,24 @@ def test_one_rank_rccl_async_all_reduce_stream_order(report):
     assert res["repro"], "the deterministic training step is not reproducible run to run"
     assert res["in_sweep"] >= 1, "no all-reduce was started from the tape hook"
     assert res["equal"], "asynchronous RCCL all-reduces changed the result: a stream dependency is missing"
+
+
+def test_bench_train_mode_under_one_rank_rccl_group(report):
+    """`bench.py --mode train` itself (BASELINE configs[2] / [3]'s line) under a ONE-rank RCCL process group: the launcher
+    contract (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*), init_process_group("nccl"), the all-gather of the rank identities
+    (`ranks_seen`: device, UUID / PCI id, RCCL version -- what lets the first N > 1 run prove that RCCL saw N devices), the
+    barrier / max-over-ranks timing and the JSON line, on one GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               TDVC_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "train", "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--train-batch", "2"], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    seen = line["ranks_seen"]
+    report(f"bench.py --mode train under a 1-rank nccl group: {line['ms_per_step']} ms/step at batch 2; ranks_seen {seen}")
+    assert line["n_gpus"] == 1 and line["value"] > 0 and len(seen) == 1
+    assert seen[0]["rank"] == 0 and seen[0]["rccl"] and (seen[0]["uuid"] or seen[0]["pci"])

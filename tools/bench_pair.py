@@ -3,6 +3,9 @@ import os
 import sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tdvc_amd import _lib
+if os.environ.get("TDVC_LIB"):          # another build of the library (tools/build_variant.sh)
+    _lib.LIB_PATH = os.path.abspath(os.environ["TDVC_LIB"])
 from tdvc_amd import ops
 
 H, W, N, reps = (int(v) for v in (sys.argv[1:5] + ["1088", "1920", "1", "20"][len(sys.argv) - 1:]))
