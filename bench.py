@@ -181,10 +181,16 @@ REP_LAUNCHES = {
                       tool=["one_pair.py", str(HP), str(WP), "6"], what="Res_Block = 2 x (3x3 64->64) fused @1088x1920"),
     "conv_row": dict(kind="conv", cin=128, cout=128, H=HP // 2, W=WP // 2, pmc=None, match="conv_row",
                      tool=["one_conv.py", "128", "128", "3", "1", str(HP // 2), str(WP // 2), "6"], what="3x3 128->128 stride 1 @544x960"),
-    "conv_mfma_v11": dict(kind="conv", cin=128, cout=64, H=HP, W=WP, pmc=None, match="conv_mfma_v11",
-                          tool=["one_conv.py", "128", "64", "3", "1", str(HP), str(WP), "6"], what="3x3 128->64 stride 1 @1088x1920"),
+    "conv_row:128->64": dict(kind="conv", kernel="conv_row", cin=128, cout=64, H=HP, W=WP, pmc=None, match="conv_row",
+                             tool=["one_conv.py", "128", "64", "3", "1", str(HP), str(WP), "6"], what="3x3 128->64 stride 1 @1088x1920 (64-column strips)"),
     "conv_mfma_v10": dict(kind="conv", cin=64, cout=216, H=HP, W=WP, pmc=None, match="conv_mfma_v10",
                           tool=["one_conv.py", "64", "216", "3", "1", str(HP), str(WP), "6"], what="3x3 64->216 stride 1 @1088x1920 (conv_offset_mask)"),
+}
+
+
+# HBM-bound operators whose traffic is measured the same way (hbm_rooflines)
+HBM_TOOLS = {
+    "dcn_fused": dict(match="dcn_lds_kernel", tool=["one_dcn.py", "6", "1.5"]),
 }
 
 
@@ -218,7 +224,7 @@ def measure_traffic(kname):
     import glob
     import shutil
     import tempfile
-    L = REP_LAUNCHES[kname]
+    L = REP_LAUNCHES[kname] if kname in REP_LAUNCHES else HBM_TOOLS[kname]
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None, "rocprofv3 not found"
@@ -273,9 +279,13 @@ def hbm_rooflines(model):
     out = {}
     P = HP * WP
 
-    def entry(ms, nbytes, what):
-        return {"what": what, "avg_launch_ms": round(ms, 4), "algorithmic_MB": round(nbytes / 1e6, 1),
-                "achieved_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak_GBps": HBM_PEAK / 1e9, "frac": round(nbytes / (ms * 1e-3) / HBM_PEAK, 4)}
+    def entry(ms, nbytes, what, name=None):
+        e = {"what": what, "avg_launch_ms": round(ms, 4), "algorithmic_MB": round(nbytes / 1e6, 1),
+             "achieved_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak_GBps": HBM_PEAK / 1e9, "frac": round(nbytes / (ms * 1e-3) / HBM_PEAK, 4)}
+        if name in LIVE_TRAFFIC and LIVE_TRAFFIC[name][0]:          # HBM bytes per launch from the PMC counters of this run
+            e["traffic"], e["traffic_source"] = LIVE_TRAFFIC[name]
+            e["traffic_over_algorithmic"] = round(LIVE_TRAFFIC[name][0] / nbytes, 3)
+        return e
 
     # (1) SPyNet warp at the finest pyramid level: x2 flow upsample + border-mode bilinear warp + 8-channel concat, one kernel
     r = ops.FM(torch.rand(1, HP, WP, 4, device=dev))
@@ -292,7 +302,7 @@ def hbm_rooflines(model):
     dcn = model.mcnet.dconv
     pc = dcn._pk("w", lambda: ops.pack_conv(dcn.weight, dcn.bias, stride=1, pad=1, ck=8 * dcn.deformable_groups, device=dcn.weight.device))
     ms = _time_launches(lambda: ops.dcn_fused(x, om, pc, y, groups=8, act=ops.ACT_LRELU, slope=0.1, round16=True))
-    out["dcn_fused"] = entry(ms, 688.0 * P, "dcn_fused @1088x1920, 8 groups, offsets ~N(0, 1.5 px) (688 B/px fp16: SURVEY 8d)")
+    out["dcn_fused"] = entry(ms, 688.0 * P, "dcn_fused @1088x1920, 8 groups, offsets ~N(0, 1.5 px) (688 B/px fp16: SURVEY 8d)", "dcn_fused")
     # (3) SELayer on a 64-channel full-resolution map: read for the pool, read for the scale, write = 3 x 64 fp16 values per pixel
     se = model.motion_est.attn
     o = ops.FM.empty(1, HP, WP, 64, device=dev)
@@ -325,6 +335,7 @@ def roofline_leg(runner):
     def rep(kname):
         """time the representative launch of one kernel: 20 back-to-back launches, HIP events on the launch stream"""
         L = REP_LAUNCHES[kname]
+        kern = L.get("kernel", kname)            # the kernel whose per-frame totals `frame_kernel` quotes
         x = ops.FM(torch.randn(1, L["H"], L["W"], L["cin"], device="cuda").half())
         P = L["H"] * L["W"]
         if L["kind"] == "pair":
@@ -355,12 +366,12 @@ def roofline_leg(runner):
                 "avg_launch_ms": round(ms, 4), "traffic": traffic,
                 "traffic_source": tsrc,
                 "hbm_side": {"algorithmic_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "peak_GBps": 8000.0, "frac": round(alg / (ms * 1e-3) / 8e12, 4)},
-                "frame_kernel": {"launches_per_frame": agg[kname]["n"], "ms_per_frame": round(agg[kname]["ms"], 3),
-                                 "tflops": round(agg[kname]["flops"] / (agg[kname]["ms"] * 1e-3) / 1e12, 2)} if kname in agg else None}
+                "frame_kernel": {"launches_per_frame": agg[kern]["n"], "ms_per_frame": round(agg[kern]["ms"], 3),
+                                 "tflops": round(agg[kern]["flops"] / (agg[kern]["ms"] * 1e-3) / 1e12, 2)} if kern in agg else None}
 
     # the dominant kernel = most milliseconds per frame among the kernels with a representative launch; the others are
     # reported beside it
-    cands = [k for k in REP_LAUNCHES if k in agg]
+    cands = [k for k in REP_LAUNCHES if "kernel" not in REP_LAUNCHES[k] and k in agg]
     name = max(cands, key=lambda k: agg[k]["ms"]) if cands else "conv_pair"
     out = {"bound": "mfma"}
     out.update(rep(name))
@@ -449,7 +460,7 @@ def main():
     if world != a.gpus:
         sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if world == 1 and a.mode == "infer" and not a.no_extras and not a.no_pmc:
-        for kname in REP_LAUNCHES:                         # child processes: must run before this process initialises the GPU
+        for kname in list(REP_LAUNCHES) + list(HBM_TOOLS):     # child processes: must run before this process initialises the GPU
             t_, src_ = measure_traffic(kname)
             LIVE_TRAFFIC[kname] = (t_, src_)
             print(f"[bench] {kname} traffic: {t_} ({src_})", file=sys.stderr, flush=True)

@@ -80,6 +80,8 @@ class Tape:
         # built WITH packed-FP32 instructions, and its softplus kernels contain the `v_pk_*_f32 ... op_sel:[0,1]` form that returned
         # wrong values next to a concurrent MFMA stream (profiles/r04_torch_packed_fp32_scan.txt)
         self.deferred: list = []
+        self.gdn_items: list = []                 # (GDN module, d gamma_eff, d beta_eff) of this sweep: one batched chain (coder.gdn_chain_batched)
+        self._ev, self._side_raw = None, None
 
     # ------------------------------------------------------------------ gradient views
     def _base(self, t: torch.Tensor) -> torch.Tensor:
@@ -115,16 +117,24 @@ class Tape:
         """run `fn` (parameter-gradient kernels reading `tensors`) on the side stream, ordered after everything issued so far"""
         if self.side is None:
             return fn()
-        main = torch.cuda.current_stream()
-        ev = torch.cuda.Event()
-        ev.record(main)
+        # one event object per tape, re-recorded per call (a wait captures the event's state at the time of the wait call); the launches
+        # inside `fn` go to the side stream by handle (ops.FORCE_STREAM) instead of through a `with torch.cuda.stream(side)` block: the
+        # event allocation and the context switch were ~15 us of Python per weight-gradient launch of a step that is bound by host time
+        ev = self._ev
+        if ev is None:
+            ev = self._ev = torch.cuda.Event()
+            self._side_raw = self.side.cuda_stream
+        ev.record()
+        self.side.wait_event(ev)
         # the operands stay referenced until the tape dies, i.e. until after join(): the caching allocator cannot hand
         # them to the main stream meanwhile (record_stream would do too, but its deferred frees made the allocator grow
-        # and stall erratically: 36 -> 60-110 ms per step in some runs)
+        # and stall erratically: 36 -> 60-110 ms per step in some runs); temporaries `fn` allocates (from the main stream's pool) likewise
         self.keep.extend(tensors)
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(ev)
+        ops.FORCE_STREAM, ops.FORCE_KEEP = self._side_raw, self.keep
+        try:
             fn()
+        finally:
+            ops.FORCE_STREAM, ops.FORCE_KEEP = None, None
 
     def release(self):
         """drop every reference the tape holds (closures, mirrors, kept operands, hooks): the hook closures refer back to
@@ -142,7 +152,7 @@ class Tape:
         reduce stages of the weight gradients collected so far go out first, on the stream their first stages ran on"""
         if self.wbatch is not None and self.wbatch.items:
             if self.side is not None:
-                with torch.cuda.stream(self.side):
+                with torch.cuda.stream(self.side):            # the job table's host-to-device copy is a torch op: a real stream context
                     self.wbatch.flush()
             else:
                 self.wbatch.flush()
@@ -358,10 +368,14 @@ def record_gdn(tape: Tape, x: FM, pc, y: FM, res, gdn):
         dbeta = torch.zeros_like(pc.bsrc)
         ops.conv_wgrad(pc, dn, x, dgamma.view(-1), scale=tape.inv_scale, square_x=True, db=dbeta)
 
-        def chain():                              # torch autograd through the reparametrisation: behind the sweep (Tape.defer)
-            owner.accumulate_param_grads(dgamma.view(dgamma.shape[0], dgamma.shape[1]), dbeta)
-            tape.touch(*owner.parameters())
-        tape.defer(chain)
+        # the chain through the reparametrisation runs behind the sweep (Tape.defer), for all GDN layers of the step at once
+        if not tape.gdn_items:
+            def chain():
+                from .model.coder import gdn_chain_batched
+                gdn_chain_batched(tape.gdn_items, param_grad)      # param_grad() also logs the touch (the virtual node behind the sweep)
+                tape.gdn_items = []
+            tape.defer(chain)
+        tape.gdn_items.append((owner, dgamma.view(dgamma.shape[0], dgamma.shape[1]), dbeta))
 
     tape.add(bwd)
 

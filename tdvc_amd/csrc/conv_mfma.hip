@@ -28,8 +28,8 @@ int launch_conv_v7(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
 bool conv_v7_eligible(const tdvc_conv_desc* d, const ConvParams& p, int Ho, int Wo);
 int launch_conv_v11(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
 bool conv_v11_eligible(const tdvc_conv_desc* d, const ConvParams& p, int Ho, int Wo);
-int launch_conv_row(const ConvParams& p, int N, hipStream_t st);
-bool conv_row_eligible(const tdvc_conv_desc* d, const ConvParams& p, int Ho, int Wo);
+int launch_conv_row(int geo, const ConvParams& p, int N, hipStream_t st);
+int conv_row_geometry(const tdvc_conv_desc* d, const ConvParams& p, int Ho, int Wo);
 int launch_conv_v10(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
 bool conv_v10_eligible(const tdvc_conv_desc* d, const ConvParams& p, int Ho, int Wo);
 int launch_conv_v9(const ConvParams& p, int ck8, int cout_tiles32, int N, hipStream_t st);
@@ -390,6 +390,7 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
     return launch_conv_v5(p, 1, d->x.N, st);
   }
   if (d->s2d) {
+    if (const int geo = conv_row_geometry(d, p, Ho, Wo); geo >= 0) { chose("conv_row(s2d)"); return launch_conv_row(geo, p, d->x.N, st); }
     TDVC_CHECK(conv_v3_eligible(d, Ho, Wo), "tdvc_conv2d: s2d conv not eligible for the stage-pipelined kernel");
     chose("conv_mfma_v3(s2d)");
     return launch_conv_v3(p, tiles / 2, d->x.N, st);
@@ -399,7 +400,7 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
   if (conv_v5_eligible(d, Ho, Wo)) { chose("conv_mfma_v5"); return launch_conv_v5(p, tiles / 2, d->x.N, st); }
   if (conv_c8_eligible(d, p, Ho, Wo)) { chose("conv_c8"); return launch_conv_c8(p, d->x.N, st); }
   if (conv_n16_eligible(d, Ho, Wo)) { chose("conv_n16"); return launch_conv_n16(p, d->x.N, st); }
-  if (conv_row_eligible(d, p, Ho, Wo)) { chose("conv_row"); return launch_conv_row(p, d->x.N, st); }
+  if (const int geo = conv_row_geometry(d, p, Ho, Wo); geo >= 0) { chose("conv_row"); return launch_conv_row(geo, p, d->x.N, st); }
   if (conv_v10_eligible(d, p, Ho, Wo)) { chose("conv_mfma_v10"); return launch_conv_v10(p, tiles / 2, d->x.N, st); }
   if (conv_v7_eligible(d, p, Ho, Wo)) { chose("conv_mfma_v7"); return launch_conv_v7(p, tiles / 2, d->x.N, st); }
   if (conv_v11_eligible(d, p, Ho, Wo)) { chose("conv_mfma_v11"); return launch_conv_v11(p, tiles / 2, d->x.N, st); }

@@ -18,8 +18,21 @@ from ._lib import (ACT_CLAMP01, ACT_LRELU, ACT_NONE, ACT_RELU, GDN_FWD, GDN_INV,
                    OUT_NHWC, OUT_SHUFFLE2)
 
 
+# The launch stream.  `torch.cuda.current_stream()` costs ~8 us of Python per call (device-index and availability checks, an os.environ
+# lookup, a Stream object): with ~2.4 k launches per training step it was a fifth of the HOST time that bounds the step
+# (tools/train_host_bound.py, tools/train_host_profile.py); the raw handle comes from the same C++ call without the wrappers.
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_cur_dev = torch._C._cuda_getDevice
+FORCE_STREAM = None       # a raw stream handle: every launch goes there instead of torch's current stream (Tape.off_path: the side
+                          # stream without the ~10 us of a `with torch.cuda.stream(...)` block per weight-gradient launch)
+FORCE_KEEP = None         # with FORCE_STREAM: a list that keeps temporaries of such launches alive (they were allocated by the main
+                          # stream's pool, which must not reuse them before the streams have joined)
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if FORCE_STREAM is not None:
+        return C.c_void_p(FORCE_STREAM)
+    return C.c_void_p(_raw_stream(_cur_dev()))
 
 
 # optional per-launch event trace (bench.py roofline leg): list of dicts, or None
@@ -44,11 +57,12 @@ class FM:
     """Feature-map view over a torch buffer `t` of shape (N, H, W, Cbuf): N images of C channels
     starting `off` elements into the buffer, batch stride `sn`, pixel stride t.stride(2)."""
 
-    __slots__ = ("t", "off", "N", "C", "H", "W", "sn", "sp")
+    __slots__ = ("t", "off", "N", "C", "H", "W", "sn", "sp", "_d")
 
     def __init__(self, t: torch.Tensor, off: int = 0, N: int | None = None, C_: int | None = None, sn: int | None = None):
         assert t.dim() == 4 and (t.shape[3] == 1 or t.stride(3) == 1)
         self.t, self.off = t, off
+        self._d = None
         self.N = t.shape[0] if N is None else N
         self.C = t.shape[3] if C_ is None else C_
         self.H, self.W = t.shape[1], t.shape[2]
@@ -89,8 +103,11 @@ class FM:
         return FM(self.t, self.off + b * self.sn, T, Cs, Cs)
 
     def desc(self) -> L.FMapDesc:
-        p = self.t.data_ptr() + self.off * self.t.element_size()
-        return L.FMapDesc(p, self.N, self.H, self.W, self.C, self.sn, self.sp, L.F32 if self.f32 else L.F16)
+        d = self._d                          # an FM is immutable: built once (struct fields are copied on assignment into descriptors)
+        if d is None:
+            p = self.t.data_ptr() + self.off * self.t.element_size()
+            d = self._d = L.FMapDesc(p, self.N, self.H, self.W, self.C, self.sn, self.sp, L.F32 if self.f32 else L.F16)
+        return d
 
     def to_nchw(self, C_=None) -> torch.Tensor:
         C_ = self.C if C_ is None else C_
@@ -281,8 +298,13 @@ class PackBatch:
         self.starts = torch.tensor(starts, dtype=torch.int32, device=dev)
 
     def run(self):
+        # a moved tensor (module.to(), a re-assigned parameter) invalidates the device job table.  The full check reads ~10 pointers of ~470
+        # layers (4 k `data_ptr()` calls: 2-3 ms of a host-bound step); the parameter and the blob of every layer each time, everything
+        # every 64th run
+        self._runs = getattr(self, "_runs", 0) + 1
+        full = (self._runs & 63) == 1
         for pc, ptrs in zip(self.pcs, self._ptrs):
-            if [t.data_ptr() for t in self._tensors(pc)] != ptrs:
+            if (([t.data_ptr() for t in self._tensors(pc)] != ptrs) if full else (pc.wsrc.data_ptr() != ptrs[0] or pc.w.data_ptr() != ptrs[7])):
                 self._build()
                 break
         L.check(L.lib().tdvc_pack_conv_weights_batch(self.jobs.data_ptr(), self.starts.data_ptr(), len(self.pcs), self.total_blocks, _stream()),
@@ -379,20 +401,28 @@ def conv_desc(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=
     else:
         Ho = (x.H + 2 * pc.pad - pc.kh) // pc.stride + 1
         Wo = (x.W + 2 * pc.pad - pc.kw) // pc.stride + 1
-    d = L.ConvDesc()
+    # the layer's part of the descriptor (weights, bias, window, taps) is built once per layer and weight form and copied per call
+    # (re-packing writes the same buffers in place; a re-allocated blob is caught by the pointer check)
+    wt = pc.packed_f32() if x.f32 else pc.w
+    key = "_tmpl32" if x.f32 else "_tmpl16"
+    tm = pc.__dict__.get(key)
+    if tm is None or tm[1] != wt.data_ptr():
+        t_ = L.ConvDesc()
+        t_.w = wt.data_ptr()
+        t_.bias = pc.bias.data_ptr()
+        t_.cout, t_.ntaps = pc.cout, len(pc.taps)
+        for i, (dy, dx) in enumerate(pc.taps):
+            t_.tap_dy[i], t_.tap_dx[i] = dy, dx
+        t_.kh, t_.kw, t_.stride, t_.pad, t_.ck = pc.kh, pc.kw, pc.stride, pc.pad, pc.ck
+        t_.s2d = int(pc.s2d)
+        tm = pc.__dict__[key] = (t_, wt.data_ptr())
+    d = L.ConvDesc.from_buffer_copy(tm[0])
     d.x = x.desc()
-    d.w = pc.packed_f32().data_ptr() if x.f32 else pc.w.data_ptr()
-    d.bias = pc.bias.data_ptr()
-    d.cout, d.ntaps = pc.cout, len(pc.taps)
-    for i, (dy, dx) in enumerate(pc.taps):
-        d.tap_dy[i], d.tap_dx[i] = dy, dx
-    d.kh, d.kw, d.stride, d.pad, d.ck = pc.kh, pc.kw, pc.stride, pc.pad, pc.ck
     d.square_input, d.gdn = int(square), gdn
     d.aux = aux.desc() if aux is not None else _NULL_FM
     d.act, d.slope, d.round_before_act = act, slope, int(round16)
     d.res = res.desc() if res is not None else _NULL_FM
     d.res2 = res2.desc() if res2 is not None else _NULL_FM
-    d.s2d = int(pc.s2d)
     d.bcast_T, d.bcast_slope = int(bcast_T), float(bcast_slope)
     if nchw_out is not None:
         assert nchw_out.shape == (x.N, pc.cout, Ho, Wo) and nchw_out.dtype == torch.float32 and nchw_out.is_contiguous()
@@ -585,8 +615,13 @@ class WgradBatch:
             C.memmove(host.data_ptr(), arr, nb_j)
             C.memmove(host.data_ptr() + nb_j, starts, nb_s)
             dev = host.to(jobs_device(jobs), non_blocking=True)
+            if torch.cuda.is_current_stream_capturing():
+                _GRAPH_KEEP.append((host, dev))          # a captured copy node re-reads the pinned table at every replay
             L.check(lib.tdvc_wgrad_reduce_batch(dev.data_ptr(), dev.data_ptr() + nb_j, n, int(starts[n]), _stream()), "wgrad_reduce_batch")
         self.items.clear()
+
+
+_GRAPH_KEEP: list = []
 
 
 def jobs_device(jobs):
@@ -608,10 +643,14 @@ def conv_wgrad(pc: PackedConv, g: FM, x: FM, dw: torch.Tensor, scale=1.0, square
     assert dw.is_cuda and dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == pc.wsrc.numel()
     lib = L.lib()
     Ho, Wo = g.H, g.W
-    nwork = lib.tdvc_conv_wgrad_work_floats(pc.cout, x.C, len(taps), x.N, Ho, Wo)
+    wk = pc.__dict__.get("_wg_static")          # per layer and geometry: workspace size, tap arrays (built once)
+    if wk is None or wk[0] != (x.C, x.N, Ho, Wo):
+        wk = pc.__dict__["_wg_static"] = ((x.C, x.N, Ho, Wo), lib.tdvc_conv_wgrad_work_floats(pc.cout, x.C, len(taps), x.N, Ho, Wo),
+                                          (C.c_int8 * len(taps))(*[t[0] for t in taps]), (C.c_int8 * len(taps))(*[t[1] for t in taps]))
+    _, nwork, dy, dxs = wk
     work = torch.empty((nwork,), dtype=torch.float32, device=dw.device)
-    dy = (C.c_int8 * len(taps))(*[t[0] for t in taps])
-    dxs = (C.c_int8 * len(taps))(*[t[1] for t in taps])
+    if FORCE_KEEP is not None:
+        FORCE_KEEP.append(work)
     dg, dxd = g.desc(), x.desc()
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -25,10 +25,17 @@ from .synth import split_optim_params
 def refresh_packed(model: torch.nn.Module) -> None:
     """after an optimizer step: every packed layer follows its (in-place updated) parameters"""
     pcs = []
-    for m in model.modules():
+    mods = model.__dict__.get("_mods_list")          # the module tree does not change between steps: walk it once
+    if mods is None:
+        mods = model.__dict__["_mods_list"] = list(model.modules())
+    from .model.coder import GDN, gdn_refresh_batched
+    pcs += gdn_refresh_batched([m for m in mods if isinstance(m, GDN)])      # effective gamma / beta of all GDN layers, re-packed with the rest
+    for m in mods:
         m.__dict__.pop("_ar_cache", None)            # coder: cached wavefront-loop descriptors (their fp32 weight twins are re-created)
+        if isinstance(m, GDN):
+            continue
         if hasattr(m, "refresh_packed"):
-            m.refresh_packed()                       # GDN (effective gamma / beta), EntropyBottleneck (packed table)
+            m.refresh_packed()                       # EntropyBottleneck (packed table)
             continue
         pk = m.__dict__.get("_packed", {})
         pcs += [pc for pc in pk.values() if isinstance(pc, ops.PackedConv)]
@@ -197,7 +204,8 @@ class TrainStep:
 
     def __call__(self, input_image: torch.Tensor, refer_frames: torch.Tensor) -> dict:
         model = self.model
-        model.train()
+        if not (model.training and model.mvCoder.training and model.resCoder.training):
+            model.train()                              # a recursive walk over ~480 modules: only when the mode actually changes
         for p in self.aux_params:
             p.grad = None
         if self.use_graph and self._eager_steps >= self.graph_warmup:

@@ -37,7 +37,7 @@ def _enable(name, on):
     from tdvc_amd import _lib
     fn = getattr(_lib.lib(), "tdvc_debug_enable_" + name)
     fn.argtypes, fn.restype = [ctypes.c_int], None
-    fn(int(on) if not isinstance(on, bool) else ((3 if name == "conv_row" else 1) if on else 0))     # conv_row: bit 0 = Cin 128, bit 1 = Cin 64
+    fn(int(on) if not isinstance(on, bool) else ((15 if name == "conv_row" else 1) if on else 0))     # conv_row: one bit per geometry (Cin 128, Cin 64, Cin 128 -> 64, stride 2)
 
 
 CASES = [
@@ -436,6 +436,9 @@ ROW_CASES += [
     ("row64_64_64_slices", 3, 64, 64, 70, 260, "relu", 0),           # batch of three, 4 full strips + 4 columns
     ("row64_64_128_two_blocks", 1, 64, 128, 96, 128, "none", 1),
     ("row64_64_64_1080p_rows", 1, 64, 64, 1088, 64, "lrelu", 1),     # one strip, 1088 rows: 256 runs of 4.25 rows
+    ("row_128_64_wide", 1, 128, 64, 100, 150, "lrelu", 0),           # Cin 128 -> 64: 64-column strips, 17-piece rows in a 6-row ring
+    ("row_128_64_wide_batch_res", 2, 128, 64, 90, 200, "none", 1),
+    ("row_128_192_wide_three_blocks", 1, 128, 192, 96, 136, "relu", 0),
 ]
 
 
@@ -471,6 +474,37 @@ def test_conv_row_pixel_shuffle(cq, H, W, nres, report):
     for _ in range(4):
         ops.conv(xf, pc, out=y, **kw)
         assert torch.equal(y.t, first), "launch-to-launch mismatch"
+
+
+@pytest.mark.parametrize("N,cout,H,W", [(1, 128, 270, 480), (2, 128, 192, 264), (1, 256, 256, 264)])
+def test_conv_row_stride2(N, cout, H, W, report):
+    """3x3 stride-2 convs with 64 input channels on the row-streaming kernel's space-to-depth geometry (512-byte ring pixels gathered from
+    two image rows, 18 of 32 fragments): against torch, and against conv_mfma_v3's space-to-depth form (same packed weights)"""
+    ops = _ops()
+    x = rnd16(randn(N, 64, H, W, seed=75))
+    w = rnd16(randn(cout, 64, 3, 3, seed=76) * 0.04)
+    b = randn(cout, seed=77) * 0.1
+    pc = ops.pack_conv(w, b, stride=2, pad=1)
+    assert pc.s2d
+    xf = to_fm(x, ops)
+    y = ops.conv(xf, pc, act=ops.ACT_LRELU, slope=0.1)
+    kern = ops.L.lib().tdvc_last_conv_kernel().decode()
+    assert kern == "conv_row(s2d)", kern
+    ref = F.leaky_relu(F.conv2d(x, w, b, stride=2, padding=1), 0.1)
+    assert_close(fm_to_cpu(y), ref, RT, AT, f"stride 2 64->{cout} @{N}x{H}x{W} on {kern}", report)
+    first = y.t.clone()
+    for _ in range(4):
+        ops.conv(xf, pc, out=y, act=ops.ACT_LRELU, slope=0.1)
+        assert torch.equal(y.t, first), "launch-to-launch mismatch"
+    _enable("conv_row", False)
+    try:
+        y3 = ops.conv(xf, pc, act=ops.ACT_LRELU, slope=0.1)
+        assert ops.L.lib().tdvc_last_conv_kernel().decode() == "conv_mfma_v3(s2d)"
+    finally:
+        _enable("conv_row", True)
+    a, c = fm_to_cpu(y), fm_to_cpu(y3)
+    report(f"conv_row(s2d) vs conv_mfma_v3(s2d): {float((a != c).float().mean()):.2e} of the outputs differ, max |d| {float((a - c).abs().max()):.2e}")
+    assert float((a - c).abs().max()) <= 4e-3
 
 
 def test_conv_row_equals_v11_arithmetic(report):

@@ -28,13 +28,15 @@ SHAPES = [
     ("64->64 @1088x1920 +res", 64, 64, 1088, 1920, False, True, 4),
     ("64->64 @544x960", 64, 64, 544, 960, False, False, 4),
     ("64->64 @272x480", 64, 64, 272, 480, False, False, 2),
+    ("128->64 @1088x1920", 128, 64, 1088, 1920, False, False, 4),
+    ("128->64 @544x960", 128, 64, 544, 960, False, False, 1),
 ]
 
 
 def enable(name, on):
     fn = getattr(ops.L.lib(), "tdvc_debug_enable_" + name)
     fn.argtypes, fn.restype = [ctypes.c_int], None
-    fn((3 if name == "conv_row" else 1) if on else 0)
+    fn((15 if name == "conv_row" else 1) if on else 0)
 
 
 def main():
@@ -85,6 +87,34 @@ def main():
         tot["other"] += med[other] * per_frame
         print(f"{name:30s} conv_row {med['conv_row']:7.1f} us = {fl / med['conv_row'] / 1e6:7.1f} TFLOP/s | {other} {med[other]:7.1f} us = "
               f"{fl / med[other] / 1e6:7.1f} TFLOP/s | x{med[other] / med['conv_row']:.3f}", flush=True)
+    # the 3x3 stride-2 convs with 64 input channels: conv_row's space-to-depth geometry against conv_mfma_v3's
+    for name, cout, H, W, per_frame in (("64->128 stride 2 @1088x1920", 128, 1088, 1920, 2), ("64->128 stride 2 @544x960", 128, 544, 960, 0)):
+        if a.only and a.only not in name:
+            continue
+        x = ops.FM(torch.randn(1, H, W, 64, device="cuda").half())
+        pc = ops.pack_conv(torch.randn(cout, 64, 3, 3) * 0.04, torch.randn(cout) * 0.1, stride=2, pad=1)
+        ys = [ops.FM.empty(1, H // 2, W // 2, cout) for _ in range(4)]
+        out = {}
+        for rnd_ in range(a.rounds):
+            for kern, row_on in (("conv_row(s2d)", True), ("conv_mfma_v3(s2d)", False)):
+                enable("conv_row", row_on)
+                ops.conv(x, pc, out=ys[0], act=ops.ACT_LRELU, slope=0.1)
+                assert ops.L.lib().tdvc_last_conv_kernel().decode() == kern
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for i in range(a.iters):
+                    ops.conv(x, pc, out=ys[i % 4], act=ops.ACT_LRELU, slope=0.1)
+                e1.record()
+                torch.cuda.synchronize()
+                out.setdefault(kern, []).append(e0.elapsed_time(e1) / a.iters * 1e3)
+        enable("conv_row", True)
+        fl = 2.0 * (H // 2) * (W // 2) * cout * 64 * 9
+        med = {k: sorted(v)[len(v) // 2] for k, v in out.items()}
+        tot["conv_row"] += med["conv_row(s2d)"] * per_frame
+        tot["other"] += med["conv_mfma_v3(s2d)"] * per_frame
+        print(f"{name:30s} conv_row {med['conv_row(s2d)']:7.1f} us = {fl / med['conv_row(s2d)'] / 1e6:7.1f} TFLOP/s | conv_mfma_v3(s2d) {med['conv_mfma_v3(s2d)']:7.1f} us = "
+              f"{fl / med['conv_mfma_v3(s2d)'] / 1e6:7.1f} TFLOP/s | x{med['conv_mfma_v3(s2d)'] / med['conv_row(s2d)']:.3f}", flush=True)
     print(f"per frame (launch counts of a 1080p P-frame): conv_row {tot['conv_row'] / 1e3:.3f} ms, conv_mfma_v11 / v10 {tot['other'] / 1e3:.3f} ms")
 
 
