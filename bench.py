@@ -383,7 +383,7 @@ def roofline_leg(runner):
     return out
 
 
-def train_measure(B, steps, warmup, rank, gpus, dev, dist, graph=False):
+def train_measure(B, steps, warmup, rank, gpus, dev, dist, graph=False, scale_update="exact"):
     """BASELINE.json configs[2] (1 GPU) / [3] (N GPUs): one optimisation step (forward, backward incl. both entropy
     models, RCCL gradient mean over ranks, clipping, Adam, aux step, re-packing) on B 256x256 P-frame samples per rank
     (weak scaling: the reference's batch 32 over 8 GPUs).  -> (seconds for `steps` steps, max over ranks; last log)"""
@@ -400,7 +400,7 @@ def train_measure(B, steps, warmup, rank, gpus, dev, dist, graph=False):
         xs.append(g[3:4])
         rs.append(ref_list([g[0:1], g[1:2], g[2:3]]))
     x, refs = torch.cat(xs), torch.cat(rs)
-    step = TrainStep(m, train_lambda=2048.0, lr=1e-4, loss_scale=128.0, graph=graph)
+    step = TrainStep(m, train_lambda=2048.0, lr=1e-4, loss_scale=128.0, graph=graph, scale_update=scale_update)
     for _ in range(2 if graph else 0):                   # eager steps that precede the capture (not part of --warmup)
         step(x, refs)
     for _ in range(warmup):
@@ -447,6 +447,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32-island, HBM-roofline and training legs of the N=1 line")
     ap.add_argument("--mode", choices=("infer", "train"), default="infer",
                     help="infer (default, the headline metric) | train: BASELINE.json configs[2]/[3], one optimisation step per step")
+    ap.add_argument("--scale-update", default="exact", choices=("exact", "lagged"),
+                    help="--mode train: when a loss-scale change reaches the host (tdvc_amd.train.TrainStep)")
     ap.add_argument("--graph", action="store_true", help="--mode train: replay the forward + backward as one captured HIP graph")
     ap.add_argument("--train-batch", type=int, default=4, help="samples per rank in --mode train (256x256 P-frames)")
     a = ap.parse_args()
@@ -480,7 +482,7 @@ def main():
             dist.destroy_process_group()
 
     if a.mode == "train":
-        dt, log = train_measure(a.train_batch, a.steps, a.warmup, rank, a.gpus, dev, dist, a.graph)
+        dt, log = train_measure(a.train_batch, a.steps, a.warmup, rank, a.gpus, dev, dist, a.graph, a.scale_update)
         finish_dist()
         if rank == 0:
             rec = train_record(a.train_batch, a.steps, a.warmup, a.gpus, dt, log)

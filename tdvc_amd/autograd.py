@@ -26,18 +26,36 @@ BATCH_WGRAD_REDUCE = True        # A/B switch (tools/ab_train.py): False = one r
 
 class MirrorPool:
     """Zeroed gradient-mirror buffers that outlive a step.  A tape takes its mirrors from the pool instead of
-    `torch.zeros_like` (211 fills, 1.5 ms of a 35 ms step); after the sweep `recycle()` re-zeroes the used ones on the
-    side stream, where the fills run under the optimizer and the next forward instead of on the backward's critical
-    path.  ~5 GB stay allocated at 4 x 256 x 256 (of 288 GB)."""
+    `torch.zeros_like` (211 fills, 1.5 ms of a 35 ms step); after the sweep `recycle()` re-zeroes them on the side stream,
+    where the fills run under the optimizer and the next forward instead of on the backward's critical path.  The mirrors are
+    carved out of a few large arenas, so the re-zeroing is one fill per arena (a step's ~280 mirrors of two dtypes took torch's
+    per-tensor path: ~280 launches from the Python thread).  ~5 GB stay allocated at 4 x 256 x 256 (of 288 GB)."""
+    ARENA_BYTES = 1 << 30
 
     def __init__(self):
         self.free: dict = {}
         self.used: list = []
+        self.arenas: list = []                    # [uint8 buffer, bytes handed out]
+        self.loose: list = []                     # mirrors that did not come from an arena (non-contiguous originals)
+
+    def _carve(self, like: torch.Tensor) -> torch.Tensor:
+        nbytes = like.numel() * like.element_size()
+        if not like.is_contiguous() or nbytes == 0:
+            t = torch.zeros_like(like)
+            self.loose.append(t)
+            return t
+        need = (nbytes + 255) & ~255
+        if not self.arenas or self.arenas[-1][1] + need > self.arenas[-1][0].numel():
+            self.arenas.append([torch.zeros(max(self.ARENA_BYTES, need), dtype=torch.uint8, device=like.device), 0])
+        ar = self.arenas[-1]
+        t = ar[0][ar[1]:ar[1] + nbytes].view(like.dtype).view(like.shape)
+        ar[1] += need
+        return t
 
     def get(self, like: torch.Tensor) -> torch.Tensor:
         key = (tuple(like.shape), like.dtype, like.device)
         lst = self.free.get(key)
-        t = lst.pop() if lst else torch.zeros_like(like)
+        t = lst.pop() if lst else self._carve(like)
         self.used.append((key, t))
         return t
 
@@ -49,7 +67,10 @@ class MirrorPool:
         with torch.cuda.stream(side):
             side.wait_event(ev)
             if self.used:
-                torch._foreach_zero_([t for _, t in self.used])      # a few multi-tensor launches instead of one fill per mirror (211 per step)
+                for buf, n in self.arenas:
+                    buf[:n].zero_()
+                for t in self.loose:
+                    t.zero_()
             for key, t in self.used:
                 self.free.setdefault(key, []).append(t)
         self.used = []

@@ -15,6 +15,9 @@ and steps identically; `GradBuckets` packs them into a few flat bu
 """
 from __future__ import annotations
 
+import gc
+from collections.abc import Mapping
+
 import torch
 import torch.distributed as dist
 
@@ -129,11 +132,69 @@ class GradBuckets:
         self._works = {}
 
 
+class StepLog(Mapping):
+    """What one TrainStep call reports: rd_loss, mse, bpp_res, bpp_mv, aux_loss, grad_norm, loss_scale (after this step's
+    update), skipped.  The step itself never waits for the GPU: the seven scalars travel to pinned host memory behind the
+    step's kernels and the first read of any key waits for that copy (the reference reads its losses every 10th iteration,
+    tools/train.py:159-163; GradScaler.step's own host read of found_inf has gone into the fused Adam kernel)."""
+    KEYS = ("rd_loss", "mse", "bpp_res", "bpp_mv", "aux_loss", "grad_norm", "loss_scale", "skipped")
+
+    def __init__(self, owner, vals):
+        self._owner, self._d, self._scale_after = owner, None, None
+        if vals.is_cuda:
+            self._host = torch.empty(7, dtype=torch.float32, pin_memory=True)
+            self._host.copy_(vals, non_blocking=True)
+            self._ev = torch.cuda.Event()
+            self._ev.record()
+        else:
+            self._host, self._ev = vals.detach().float(), None
+
+    def _arrived(self, block):
+        if self._ev is not None:
+            if not block and not self._ev.query():
+                return False
+            self._ev.synchronize()
+            self._ev = None
+        return True
+
+    def _vals(self):
+        if self._d is None:
+            if self._scale_after is None:
+                self._owner._settle(self)
+            v = self._host.tolist()
+            skipped = v[6] != 0.0
+            self._d = dict(rd_loss=v[0], mse=v[1], bpp_res=v[2], bpp_mv=v[3], aux_loss=v[4],
+                           grad_norm=float("nan") if skipped else v[5], loss_scale=self._scale_after, skipped=skipped)
+            self._owner = None
+        return self._d
+
+    def __getitem__(self, k):
+        return self._vals()[k]
+
+    def __iter__(self):
+        return iter(self.KEYS)
+
+    def __len__(self):
+        return len(self.KEYS)
+
+    def __repr__(self):
+        return f"StepLog({self._vals()!r})"
+
+
 class TrainStep:
     def __init__(self, model, train_lambda: float = 2048.0, lr: float = 1e-4, loss_scale: float = 1024.0, clip: float = 2.0,
                  dynamic_scale: bool = True, growth_interval: int = 2000, graph: bool = False, graph_warmup: int = 2,
-                 side_stream: bool = True):
-        """graph=True: after `graph_warmup` eager steps (they build every lazily packed form) the forward + backward of
+                 side_stream: bool = True, scale_update: str = "exact", freeze_gc: bool = True):
+        """freeze_gc: after the third step (model, packed weights, descriptor caches and pools exist by then) everything alive
+        moves to the garbage collector's permanent generation (gc.freeze): a step allocates ~50 k short-lived containers (tape
+        closures, descriptors), which triggers full collections, and each of those walked the whole heap of the process --
+        40-75 ms once or twice per 30 steps (+2.3 ms per step on average, tools/train_back_to_back.py).
+        scale_update: "exact" = GradScaler.update()'s timing: a step that overflowed halves the scale before the NEXT
+        forward (the host waits, at the start of a step, for the previous step's flag -- by then the GPU still holds that
+        step's optimizer / refresh kernels, so the wait does not drain it); "lagged" = never wait: the update lands on
+        the first step that starts after the flag has arrived (one or two steps late; the overflowed steps in between are
+        still skipped exactly, by the flag on the device).  With dynamic_scale=False nothing ever waits.
+        graph=True: after `graph_warmup` eager steps (they build every lazily packed form) the forward + backward of
         one step is captured into a HIP graph and replayed: ~2300 launches leave the Python interpreter's critical
         path.  Input shapes are then fixed; a loss-scale change re-captures."""
         self.model = model
@@ -150,12 +211,16 @@ class TrainStep:
         # torch.cuda.amp.GradScaler's policy (train.py:101,146-149): skip the step and halve the scale when a gradient is
         # not finite, double it after `growth_interval` clean steps
         self.dynamic_scale, self.growth_interval, self._clean_steps = bool(dynamic_scale), int(growth_interval), 0
+        assert scale_update in ("exact", "lagged")
+        self.scale_update, self._pending = scale_update, []
+        self.freeze_gc, self._calls = bool(freeze_gc), 0
         main, aux = split_optim_params(model)
         named = dict(model.named_parameters())
         self.main_params = [named[n] for n in main]
         self.aux_params = [named[n] for n in aux]
         self.buckets = GradBuckets(self.main_params)
         fused = all(p.is_cuda for p in self.main_params + self.aux_params)          # one multi-tensor kernel per step
+        self._fused = fused
         self.optimizer = torch.optim.Adam(self.main_params, lr=lr, fused=fused)
         self.aux_optimizer = torch.optim.Adam(self.aux_params, lr=10 * lr, fused=fused)          # utils.py:110-112
 
@@ -204,6 +269,11 @@ class TrainStep:
 
     def __call__(self, input_image: torch.Tensor, refer_frames: torch.Tensor) -> dict:
         model = self.model
+        self._calls += 1
+        if self._calls == 4 and self.freeze_gc:
+            gc.collect()
+            gc.freeze()
+        self._settle(block=self.dynamic_scale and self.scale_update == "exact")
         if not (model.training and model.mvCoder.training and model.resCoder.training):
             model.train()                              # a recursive walk over ~480 modules: only when the mode actually changes
         for p in self.aux_params:
@@ -224,24 +294,46 @@ class TrainStep:
         # clip_grad_norm_(main params, clip) on the flat buckets: the global 2-norm is also the finiteness test (after the
         # mean, so every rank agrees)
         gnorm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(b) for b in self.buckets.buckets]))
-        finite = bool(torch.isfinite(gnorm))
-        if finite:
-            coef = torch.clamp(self.clip / (gnorm + 1e-6), max=1.0)
-            for b in self.buckets.buckets:
-                b.mul_(coef)
+        coef = torch.clamp(self.clip / (gnorm + 1e-6), max=1.0)
+        if self._fused:
+            # no host round trip: the fused Adam kernel itself skips the update (and its step counter) when `found_inf` is
+            # set -- what GradScaler.step does for a fused optimizer; the host learns about it from the StepLog's copy
+            found = torch.logical_not(torch.isfinite(gnorm)).float()
+            torch._foreach_mul_(self.buckets.buckets, coef)
+            self.optimizer.found_inf = found
             self.optimizer.step()
-            self._clean_steps += 1
-            if self.dynamic_scale and self._clean_steps % self.growth_interval == 0:
-                self.loss_scale *= 2.0
         else:
-            gnorm = torch.tensor(float("nan"))
-            if self.dynamic_scale:
-                self.loss_scale *= 0.5
-                self._clean_steps = 0
+            found = torch.logical_not(torch.isfinite(gnorm)).float()
+            if not bool(found):
+                for b in self.buckets.buckets:
+                    b.mul_(coef)
+                self.optimizer.step()
         aux = model.mvCoder.aux_loss() + model.resCoder.aux_loss()      # pnet.py's forward returns exactly these two
         aux.backward()
         self.aux_optimizer.step()
         refresh_packed(model)
-        return dict(rd_loss=float(self.lam * mse + bpp_res + bpp_mv), mse=float(mse), bpp_res=float(bpp_res),
-                    bpp_mv=float(bpp_mv), aux_loss=float(aux.detach()), grad_norm=float(gnorm), loss_scale=self.loss_scale,
-                    skipped=not finite)
+        vals = torch.stack([self.lam * mse + bpp_res + bpp_mv, mse, bpp_res, bpp_mv, aux.detach().float(), gnorm, found])
+        log = StepLog(self, vals)
+        self._pending.append(log)
+        if not vals.is_cuda:
+            self._settle(log)
+        return log
+
+    def _settle(self, upto=None, block: bool = True):
+        """apply GradScaler.update()'s bookkeeping for the steps whose finiteness flag has reached the host, oldest first:
+        up to `upto` (all of them when None); block=False stops at the first step the GPU has not finished"""
+        while self._pending:
+            log = self._pending[0]
+            if not log._arrived(block):
+                return
+            self._pending.pop(0)
+            if log._host[6] == 0.0:
+                self._clean_steps += 1
+                if self.dynamic_scale and self._clean_steps % self.growth_interval == 0:
+                    self.loss_scale *= 2.0
+            elif self.dynamic_scale:
+                self.loss_scale *= 0.5
+                self._clean_steps = 0
+            log._scale_after = self.loss_scale
+            if log is upto:
+                return
