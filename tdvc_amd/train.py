@@ -234,8 +234,6 @@ class TrainStep:
         B, _, H, W = input_image.shape
         self.buckets.zero()
         pool = self._pool if (self.use_pool and self._side is not None and not capturing) else None
-        if pool is not None:
-            torch.cuda.current_stream().wait_stream(self._side)          # last step's re-zeroing of the mirrors
         with autograd.record(self.loss_scale, side_stream=self._side, pool=pool) as tape:
             if self._ready is None:
                 tape.touch_log = {}                                  # first step: learn when each gradient is final
@@ -244,6 +242,10 @@ class TrainStep:
                 tape.on_node_done = lambda k: self._node_done(tape, k)
             recon, bpp_res, bpp_mv, _, _ = self.model(input_image, refer_frames, True)
             diff = recon - input_image.float()
+            if pool is not None:
+                # last step's re-zeroing of the mirrors (5 GB of fills on the side stream) has the optimizer, the re-packing and this
+                # forward to finish under: nothing before this line writes a mirror
+                torch.cuda.current_stream().wait_stream(self._side)
             # d(lambda * MSE)/d recon, scaled; the rate terms are seeded through tape.rate_grad
             tape.grad_tensor(recon).copy_(diff * (2.0 * self.lam * self.loss_scale / diff.numel()))
             tape.rate_grad = 1.0 / float(B * H * W)

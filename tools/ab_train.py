@@ -28,7 +28,7 @@ step = TrainStep(m, loss_scale=128.0)
 for _ in range(5):
     step(x, refs)
 res = {repr(va): [], repr(vb): []}
-for rnd in range(4):
+for rnd in range(int(os.environ.get("AB_ROUNDS", "4"))):
     for v in (va, vb):
         if attr == "exec":
             exec(v)
@@ -37,6 +37,14 @@ for rnd in range(4):
         for _ in range(3):
             step(x, refs)
         torch.cuda.synchronize()
+        if os.environ.get("AB_BACK_TO_BACK", "1") == "1":          # blocks of 10 steps, no host read in between (how bench.py times them)
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    step(x, refs)
+                torch.cuda.synchronize()
+                res[repr(v)].append((time.perf_counter() - t0) * 1e2)
+            continue
         for _ in range(15):
             t0 = time.perf_counter()
             step(x, refs)
