@@ -81,6 +81,10 @@ typedef struct {
                              conv + `out + temporal` + LeakyReLU (pnet.py:304-314) as ONE pass over the 4-frame buffer.  The conv
                              input may be channels of the same buffer (a 1x1 conv reads only the pixels it then overwrites). */
   float bcast_slope;
+  float* chan_sum;        /* ABI 4.  not NULL: next to storing y the launch writes partial per-channel sums of the STORED fp16 values,
+                             chan_sum[n][row][cout] for row < tdvc_conv_chan_sum_rows(d) (fp32; every row is written) -- the
+                             SELayer's global average pool (inflate.py:204) without a second pass over y.  Only the convs for which
+                             tdvc_conv_chan_sum_rows() returns > 0 accept it. */
 } tdvc_conv_desc;
 
 /* ---------------------------------------------------------------- library */
@@ -113,6 +117,9 @@ int64_t tdvc_conv_packed_bytes(int cout, int cin, int ntaps, int ck);
 int tdvc_pack_conv_weights(const float* w_oihw, int cout, int cin_real, int cin, int kh, int kw,
                            int ntaps, const int8_t* tap_dy, const int8_t* tap_dx, int ck, uint16_t* dst);
 int tdvc_conv2d(const tdvc_conv_desc* d, void* stream);
+/* Rows per image of tdvc_conv_desc::chan_sum this conv would write, 0 when its kernel has no fused channel sum (the caller then
+ * runs tdvc_channel_sum over y), < 0 on a malformed descriptor.  `chan_sum` itself is ignored here. */
+int tdvc_conv_chan_sum_rows(const tdvc_conv_desc* d);
 /* The fp32 islands: main/model/pnet.py:33-49,57-73 run both coders with autocast OFF (and enabled_amp=False runs the
  * whole model fp32).  Same descriptor with an fp32 input fmap (C %% 8 == 0) and `w` = the fp32 packing below; fp32
  * accumulation on v_mfma_f32_32x32x2_f32; aux / residual / output fmaps fp32 or fp16.  tdvc_conv2d forwards here

@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
                 ("ck", C.c_int32), ("square_input", C.c_int32), ("gdn", C.c_int32),
                 ("aux", FMapDesc), ("act", C.c_int32), ("slope", C.c_float),
                 ("round_before_act", C.c_int32), ("res", FMapDesc), ("res2", FMapDesc), ("out_mode", C.c_int32), ("s2d", C.c_int32),
-                ("bcast_T", C.c_int32), ("bcast_slope", C.c_float)]
+                ("bcast_T", C.c_int32), ("bcast_slope", C.c_float), ("chan_sum", C.c_void_p)]
 
 
 class DcnDesc(C.Structure):
@@ -58,6 +58,7 @@ _i, _f, _i64 = C.c_int, C.c_float, C.c_int64
 # name -> (restype, argtypes); every symbol declared in include/tdvc_hip.h
 SIGNATURES = {
     "tdvc_abi_version": (_i, []),
+    "tdvc_conv_chan_sum_rows": (_i, [C.POINTER(ConvDesc)]),
     "tdvc_last_error": (C.c_char_p, []),
     "tdvc_last_conv_kernel": (C.c_char_p, []),
     "tdvc_prepare_device": (_i, []),

@@ -18,6 +18,7 @@ struct ConvParams {
   int s2d, Corig;       // space-to-depth view of a stride-2 conv (v3 only): Corig = channels per parity
   int reverse;          // walk the tile raster backwards (alternate launches: see tdvc_conv2d, "Infinity Cache")
   int bcast_T; float bcast_slope;   // conv_mfma_v5 only: y[:, t] = lrelu(y[:, t] + conv) over bcast_T slices (tdvc_conv_desc::bcast_T)
+  float* csum;                      // conv_mfma_v5 only: partial channel sums of the stored values (tdvc_conv_desc::chan_sum), or null
   int8_t tap_dy[TDVC_MAX_TAPS], tap_dx[TDVC_MAX_TAPS];
 };
 
@@ -283,9 +284,11 @@ __device__ __forceinline__ void epilogue_store_row(const ConvParams& p, const Pa
 // BCAST (conv_mfma_v5, tdvc_conv_desc::bcast_T == 4): the row is not stored; it is added to the four 64-channel slices that
 // start at y and LeakyReLU'd in place, with the arithmetic of bcast_add_act_kernel (fp32 add of the two fp16 values,
 // v > 0 ? v : v * slope, one rounding) -- bit-identical to the conv followed by tdvc_bcast_add_act.
-template <int NTX, bool BIAS_IN_ACC, bool BCAST = false>
+// CSUM (conv_mfma_v5, tdvc_conv_desc::chan_sum): the lane also adds the values it stores (channels 8 (lane & 7) .. + 8 of four pixels per row)
+// into cs[0..7].
+template <int NTX, bool BIAS_IN_ACC, bool BCAST = false, bool CSUM = false>
 __device__ __forceinline__ void epilogue_lean_seq(const ConvParams& p, f32x16 (&acc)[2][NTX], const float* bias64, unsigned char* ew, int n,
-                                                  int cbase, int oy_first, int ox_first, int lane, bool zero_acc, bool full) {
+                                                  int cbase, int oy_first, int ox_first, int lane, bool zero_acc, bool full, float* cs = nullptr) {
   constexpr int EPS = 144;
   const int hh = lane >> 5, r = lane & 31;
   const int chunk = lane & 7, prow = lane >> 3;
@@ -377,6 +380,10 @@ __device__ __forceinline__ void epilogue_lean_seq(const ConvParams& p, f32x16 (&
       if (has1) v = v + r1[k];
       if (has2) v = v + r2[k];
       if (ok[k]) *reinterpret_cast<half8*>(yb + (long)opix[k] * p.y.sp) = v;
+      if constexpr (CSUM) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs[j] += ok[k] ? (float)v[j] : 0.f;
+      }
     }
   }
 }

@@ -24,6 +24,7 @@ int launch_conv_v3(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
 bool conv_v3_eligible(const tdvc_conv_desc* d, int Ho, int Wo);
 int launch_conv_v5(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
 bool conv_v5_eligible(const tdvc_conv_desc* d, int Ho, int Wo);
+int conv_v5_chan_sum_rows(int Ho, int Wo, int cout_blocks, int N);
 int launch_conv_v7(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
 bool conv_v7_eligible(const tdvc_conv_desc* d, const ConvParams& p, int Ho, int Wo);
 int launch_conv_v11(const ConvParams& p, int cout_blocks, int N, hipStream_t st);
@@ -290,9 +291,12 @@ static int next_walk_reverse() {
   return g_walk_mode == 1 ? (int)(g_walk_parity++ & 1u) : 0;
 }
 
-extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
+// query_rows: validate and dispatch as tdvc_conv2d would, but return the rows of tdvc_conv_desc::chan_sum instead of launching
+static int conv2d_impl(const tdvc_conv_desc* d, void* stream, bool query_rows) {
   TDVC_CHECK(d, "tdvc_conv2d: null descriptor");
   if (d->x.dtype == TDVC_F32) {           // fp32 islands (pnet.py:33,57): fp32 activations + fp32 packing -> conv_f32.hip
+    if (query_rows) return 0;
+    TDVC_CHECK(!d->chan_sum, "tdvc_conv2d: chan_sum is not available on the fp32 path (tdvc_conv_chan_sum_rows() == 0)");
     snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_f32");
     return tdvc_conv2d_f32(d, stream);
   }
@@ -369,12 +373,22 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
   memcpy(p.tap_dx, d->tap_dx, sizeof(p.tap_dx));
   const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
   p.tiles_x = tiles_x;
-  p.reverse = next_walk_reverse();
+  p.reverse = query_rows ? 0 : next_walk_reverse();
+  p.csum = nullptr;
   const int tiles = cout_tiles(d->cout);
   const int mt = tiles == 1 ? 1 : 2;
   if (mt == 2 && convk::conv_is_simple(p)) {
     p.simple = convk::conv_is_lean(p) ? 2 : 1;       // 2: the lean packed-fp16 form of the transposed epilogue (conv_common.h)
     p.slope = convk::conv_simple_slope(p);
+  }
+  {
+    // fused channel sums (tdvc_conv_desc::chan_sum): the lean epilogue of conv_mfma_v5 with one block of 64 output channels
+    const bool csum_ok = !d->bcast_T && !d->s2d && tiles == 2 && p.simple == 2 && !conv_v9_eligible(d, Ho, Wo, conv_v3_eligible(d, Ho, Wo)) &&
+                         !gdn128_eligible(d, p, Ho, Wo) && conv_v5_eligible(d, Ho, Wo);
+    if (query_rows) return csum_ok ? conv_v5_chan_sum_rows(Ho, Wo, 1, d->x.N) : 0;
+    TDVC_CHECK(!d->chan_sum || (csum_ok && (reinterpret_cast<uintptr_t>(d->chan_sum) & 15) == 0),
+               "tdvc_conv2d: chan_sum on a conv whose kernel has no fused channel sum (tdvc_conv_chan_sum_rows() == 0) or unaligned");
+    p.csum = d->chan_sum;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   auto chose = [](const char* name) { snprintf(g_last_kernel, sizeof(g_last_kernel), "%s", name); };
@@ -417,5 +431,8 @@ extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) {
     default: return launch_m<8>(p, mt, d->stride, grid, lds_v1, st);
   }
 }
+
+extern "C" int tdvc_conv2d(const tdvc_conv_desc* d, void* stream) { return conv2d_impl(d, stream, false); }
+extern "C" int tdvc_conv_chan_sum_rows(const tdvc_conv_desc* d) { return conv2d_impl(d, nullptr, true); }
 
 extern "C" const char* tdvc_last_conv_kernel(void) { return g_last_kernel; }

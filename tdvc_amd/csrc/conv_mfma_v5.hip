@@ -113,6 +113,7 @@ __global__ __launch_bounds__(NTHR5, 1) void conv_mfma_v5_kernel(const ConvParams
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // tdvc_conv_desc::chan_sum: this lane's channels 8 (lane & 7) .. + 8 over the pixels it stored
   issue(I0{}, 0);
   if (nstages > 1) issue(I1{}, 1);
 
@@ -162,7 +163,8 @@ __global__ __launch_bounds__(NTHR5, 1) void conv_mfma_v5_kernel(const ConvParams
       } else if constexpr (SIMPLE) {
         // the private tile doubles as the transpose scratch (this wave's reads of it are complete:
         // every fragment read was waited for before its MFMA)
-        convk::epilogue_simple_rows<WR, false, SIMPLE>(p, acc, bias_s, tbuf, n, cb * 64, oy0, tx * TW5, lane, true);
+        if (SIMPLE == 2 && p.csum) convk::epilogue_lean_seq<WR, false, false, true>(p, acc, bias_s, tbuf, n, cb * 64, oy0, tx * TW5, lane, true, false, cs);
+        else convk::epilogue_simple_rows<WR, false, SIMPLE>(p, acc, bias_s, tbuf, n, cb * 64, oy0, tx * TW5, lane, true);
       } else {
         const int ox = tx * TW5 + r;
 #pragma unroll
@@ -187,6 +189,20 @@ __global__ __launch_bounds__(NTHR5, 1) void conv_mfma_v5_kernel(const ConvParams
   for (int S = 0; S < nstages; S += 2) {
     stage(I0{}, S);
     if (S + 1 < nstages) stage(I1{}, S + 1);
+  }
+  if (SIMPLE == 2 && p.csum) {
+    // the eight lanes with the same lane & 7 hold the same channels: fixed-order butterfly, then one row per (workgroup, wave)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      cs[j] += __shfl_xor(cs[j], 8);
+      cs[j] += __shfl_xor(cs[j], 16);
+      cs[j] += __shfl_xor(cs[j], 32);
+    }
+    if (lane < 8) {
+      float* o = p.csum + (((long)n * gridDim.x + blockIdx.x) * NWAVE + wave) * 64 + lane * 8;
+      *reinterpret_cast<f32x4*>(o) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+      *reinterpret_cast<f32x4*>(o + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
+    }
   }
 }
 
@@ -232,6 +248,17 @@ bool conv_v5_eligible(const tdvc_conv_desc* d, int Ho, int Wo) {
          v5_lds_bytes(d->kh, d->kw, d->ntaps, nchunks) <= 160 * 1024;
 }
 
+// workgroups along x for a launch over `nbtiles` tiles (also the row count of tdvc_conv_desc::chan_sum: 8 waves per workgroup)
+static int v5_grid_x(int nbtiles, int cout_blocks, int N) {
+  int gx = 256 / (cout_blocks * N);
+  if (gx < 1) gx = 1;
+  return gx > nbtiles ? nbtiles : gx;
+}
+int conv_v5_chan_sum_rows(int Ho, int Wo, int cout_blocks, int N) {
+  const int nbtiles = ((Wo + TW5 - 1) / TW5) * ((Ho + WR * NWAVE - 1) / (WR * NWAVE));
+  return v5_grid_x(nbtiles, cout_blocks, N) * NWAVE;
+}
+
 int launch_conv_v5(const ConvParams& p, int cout_blocks, int N, hipStream_t st) {
   ConvParams q = p;
   q.tiles_x = (p.Wo + TW5 - 1) / TW5;
@@ -242,10 +269,7 @@ int launch_conv_v5(const ConvParams& p, int cout_blocks, int N, hipStream_t st) 
   const int lds = v5_lds_bytes(p.kh, p.kw, p.ntaps, p.nchunks);
   const bool simple = convk::conv_is_simple(p);
   if (simple) q.slope = convk::conv_simple_slope(p);
-  int gx = 256 / (cout_blocks * N);
-  if (gx < 1) gx = 1;
-  if (gx > e.nbtiles) gx = e.nbtiles;
-  dim3 grid(gx, cout_blocks, N);
+  dim3 grid(v5_grid_x(e.nbtiles, cout_blocks, N), cout_blocks, N);
   const int tl = v5_tl(p.kh, p.kw);
   if (tl == 4) return launch_tl<4>(q, e, p.bcast_T ? 4 : (simple ? (convk::conv_is_lean(p) ? 2 : 1) : 0), grid, lds, st);
   tdvc_set_error("conv v5: unsupported window %dx%d", p.kh, p.kw);

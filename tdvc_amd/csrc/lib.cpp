@@ -16,7 +16,7 @@ void tdvc_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int tdvc_abi_version(void) { return 3; }   // 3: tdvc_prepare_device, SE-pool conv epilogue, deterministic col2im
+extern "C" int tdvc_abi_version(void) { return 4; }   // 4: tdvc_conv_desc::chan_sum; 3: tdvc_prepare_device, SE-pool conv epilogue, deterministic col2im
 extern "C" const char* tdvc_last_error(void) { return g_err; }
 
 // ---- per-device scratch: a page of zeros nobody writes (DMA source of out-of-image halo pixels) and a dump page nobody

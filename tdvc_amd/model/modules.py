@@ -75,12 +75,13 @@ class SELayer(nn.Module, PackCache):
                                 params=(self.conv1.conv.weight, self.conv1.conv.bias, self.conv2.conv.weight, self.conv2.conv.bias))
         return self._pk("se", build)
 
-    def gate(self, x: FM) -> torch.Tensor:
-        return ops.se_gate(x, self.params())
+    def gate(self, x: FM, partial=None) -> torch.Tensor:
+        return ops.se_gate(x, self.params(), partial=partial)
 
-    def run(self, x: FM, out: FM | None = None, act=ACT_NONE, slope=0.0, res: FM | None = None, out2: FM | None = None):
+    def run(self, x: FM, out: FM | None = None, act=ACT_NONE, slope=0.0, res: FM | None = None, out2: FM | None = None, sums: list | None = None):
+        """`sums`: what `ops.conv(..., chan_sum=sums)` left when it produced `x` (empty: no fused sums, one more pass over x)"""
         out = FM.empty(x.N, x.H, x.W, x.C, dtype=x.t.dtype, device=x.t.device) if out is None else out
-        return ops.scale_act_res(x, out, gate=self.gate(x), act=act, slope=slope, res=res, out2=out2)
+        return ops.scale_act_res(x, out, gate=self.gate(x, sums[0] if sums else None), act=act, slope=slope, res=res, out2=out2)
 
 
 class Res_Block(nn.Module, PackCache):
@@ -243,8 +244,9 @@ class OffsetGen(nn.Module, PackCache):
         if ops.TAPE is not None:
             off = ops.clone(off)      # keep the fusion conv's own output (LeakyReLU sign) for the backward pass
         ops.add_flow(off, flow)
-        e = ops.conv(off, pk_conv(self, "ff_", self.feat_fusion_))
-        return self.attn.run(e)
+        sums = []
+        e = ops.conv(off, pk_conv(self, "ff_", self.feat_fusion_), chan_sum=sums)
+        return self.attn.run(e, sums=sums)
 
 
 class DCN(nn.Module, PackCache):
@@ -372,8 +374,9 @@ class LoopFilter(nn.Module, PackCache):
         # inference re-uses `bf` for the block output; under the tape `bf` is still needed by the backward of `bs`
         o = bf if ops.TAPE is None else FM.empty(B, H, W, 256, device=dev)
         self._slices("b3", l1.conv3, s, o, res_buf=a)
-        f = ops.conv(o, pk_conv(self, "ff", self.feat_fusion), **lr)
-        return self.attn.run(f, out=out, res=xt.ch(192, 64))
+        sums = []
+        f = ops.conv(o, pk_conv(self, "ff", self.feat_fusion), chan_sum=sums, **lr)
+        return self.attn.run(f, out=out, res=xt.ch(192, 64), sums=sums)
 
 
 class FeatureExtract(nn.Module, PackCache):
@@ -423,8 +426,9 @@ class FeatureFix(nn.Module, PackCache):
         cat = FM.empty(B, H, W, 128, device=dev)          # [fin*cor | out*cor]
         ops.match_gather(fin, fref, idx, scale, cat)
         ops.conv(cat, pk_conv(self, "ff", self.featfusion), out=y.ch(0, 64), **lr)
-        o2 = ops.conv(y, pk_conv(self, "ff2", self.featfusion2))
-        o2 = self.attn.run(o2, **lr)
+        sums = []
+        o2 = ops.conv(y, pk_conv(self, "ff2", self.featfusion2), chan_sum=sums)
+        o2 = self.attn.run(o2, sums=sums, **lr)
         o = run_stack(self.recon_layer, o2, res2=x)
         rgb = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
         ops.conv(o, pk_conv(self, "down", self.featdown), act=ops.ACT_CLAMP01, nchw_out=rgb)

@@ -446,10 +446,19 @@ def conv_desc(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=
 
 def conv(x: FM, pc: PackedConv, out: FM | None = None, act=ACT_NONE, slope=0.0, res: FM | None = None,
          res2: FM | None = None, gdn=GDN_NONE, aux: FM | None = None, square=False, out_dtype=None,
-         round16=False, nchw_out: torch.Tensor | None = None, bcast_T=0, bcast_slope=0.0) -> FM | torch.Tensor:
+         round16=False, nchw_out: torch.Tensor | None = None, bcast_T=0, bcast_slope=0.0, chan_sum: list | None = None) -> FM | torch.Tensor:
     """`bcast_T` (inference only): the conv result is not stored but broadcast-added, with LeakyReLU(bcast_slope), over the
-    bcast_T channel slices that start at `out` (tdvc_conv_desc::bcast_T)"""
+    bcast_T channel slices that start at `out` (tdvc_conv_desc::bcast_T).
+    `chan_sum` (inference only): a list; when the kernel this conv dispatches to can sum the values it stores per channel
+    (tdvc_conv_desc::chan_sum), (partial [N][rows][cout] fp32, rows) is appended -- the input of `se_gate(..., partial=)`;
+    left empty otherwise (the caller then sums with tdvc_channel_sum)."""
     d, ret, Ho, Wo, pc, rec_pc = conv_desc(x, pc, out, act, slope, res, res2, gdn, aux, square, out_dtype, round16, nchw_out, bcast_T, bcast_slope)
+    if chan_sum is not None and TAPE is None and FUSE_CHAN_SUM:
+        rows = L.lib().tdvc_conv_chan_sum_rows(C.byref(d))
+        if rows > 0:
+            part = torch.empty((x.N, rows, pc.cout), dtype=torch.float32, device=x.t.device)
+            d.chan_sum = part.data_ptr()
+            chan_sum.append((part, rows))
     if x.f32 and TAPE is not None and not _IN_BACKWARD:
         raise L.TdvcHipError("conv: the fp32 form has no backward (the fp32 islands are an inference / coding mode)")
     if bcast_T and TAPE is not None and not _IN_BACKWARD:
@@ -897,15 +906,23 @@ class SEParams:
     params: tuple = ()       # the four nn.Parameters (gradient accumulators), same storage as w1 / b1 / w2 / b2
 
 
-def se_gate(x: FM, p: SEParams) -> torch.Tensor:
-    """gate[N][C] fp32 (`main/model/inflate.py:204-208` without the final multiply)."""
+FUSE_CHAN_SUM = True           # A/B switch: the SELayer's channel sums from the producing conv's epilogue (conv(..., chan_sum=[]))
+
+
+def se_gate(x: FM, p: SEParams, partial=None) -> torch.Tensor:
+    """gate[N][C] fp32 (`main/model/inflate.py:204-208` without the final multiply).  `partial` = (tensor [N][rows][C], rows): the
+    channel sums of `x` that its producer already wrote (conv(..., chan_sum=)); otherwise one pass over x (tdvc_channel_sum)."""
     npix = x.H * x.W
-    nblocks = max(1, min(1024, npix // 256))      # 4 workgroups per CU at full resolution: 64 KB of loads in flight per CU
-    partial = torch.empty((x.N, nblocks, x.C), dtype=torch.float32, device=x.t.device)
     gate = torch.empty((x.N, x.C), dtype=torch.float32, device=x.t.device)
-    dx = x.desc()
     lib = L.lib()
-    L.check(lib.tdvc_channel_sum(C.byref(dx), partial.data_ptr(), nblocks, _stream()), "channel_sum")
+    if partial is not None:
+        partial, nblocks = partial
+        assert tuple(partial.shape) == (x.N, nblocks, x.C) and partial.dtype == torch.float32
+    else:
+        nblocks = max(1, min(1024, npix // 256))      # 4 workgroups per CU at full resolution: 64 KB of loads in flight per CU
+        partial = torch.empty((x.N, nblocks, x.C), dtype=torch.float32, device=x.t.device)
+        dx = x.desc()
+        L.check(lib.tdvc_channel_sum(C.byref(dx), partial.data_ptr(), nblocks, _stream()), "channel_sum")
     L.check(lib.tdvc_se_gate(partial.data_ptr(), nblocks, 1.0 / npix, x.N, p.C, p.Cmid, p.w1.data_ptr(),
                              p.b1.data_ptr(), p.w2.data_ptr(), p.b2.data_ptr(), gate.data_ptr(), _stream()), "se_gate")
     _rec("se_gate", x, p, partial, nblocks, gate)

@@ -660,6 +660,43 @@ def test_conv_bcast_add_act_fused(report):
     assert_close(gb, ref, RT, AT, "fused temporal conv + broadcast add", report)
 
 
+@pytest.mark.parametrize("cin,act,with_res,B,H,W", [(128, False, False, 1, 96, 160), (256, True, True, 2, 90, 101), (128, False, True, 1, 136, 240)])
+def test_conv_fused_channel_sums(cin, act, with_res, B, H, W, report):
+    """tdvc_conv_desc::chan_sum: the 1x1 convs in front of the three full-resolution SELayers (OffsetGen.feat_fusion_, LoopFilter.feat_fusion,
+    FeatureFix.featfusion2) leave the per-channel sums of the values they store -- the SELayer's average pool (inflate.py:204) -- next to y.
+    The output is bit-equal to the plain launch, the sums are those of the stored fp16 values (ragged tile edges, batch 2, activation and
+    residual in the epilogue), and se_gate() on them equals se_gate() on a separate pass over y to fp32 summation order."""
+    ops = _ops()
+    x = rnd16(randn(B, cin, H, W, seed=91))
+    w = rnd16(randn(64, cin, 1, 1, seed=92) * (1.0 / cin ** 0.5))
+    bias = randn(64, seed=93) * 0.1
+    r = rnd16(randn(B, 64, H, W, seed=94)) if with_res else None
+    pc = ops.pack_conv(w, bias, stride=1, pad=0)
+    kw = dict(act=ops.ACT_LRELU if act else ops.ACT_NONE, slope=0.1 if act else 0.0, res=to_fm(r, ops) if with_res else None)
+    xf = to_fm(x, ops)
+    plain = ops.conv(xf, pc, **kw)
+    sums = []
+    fused = ops.conv(xf, pc, chan_sum=sums, **kw)
+    name = ops.L.lib().tdvc_last_conv_kernel().decode()
+    assert name == "conv_mfma_v5" and len(sums) == 1
+    part, rows = sums[0]
+    assert tuple(part.shape) == (B, rows, 64)
+    y = fm_to_cpu(fused)
+    assert torch.equal(y, fm_to_cpu(plain))
+    want = y.double().sum(dim=(2, 3))
+    got = part.double().sum(dim=1).cpu()
+    err = float(((got - want).abs() / (want.abs() + 1.0)).max())
+    report(f"fused channel sums {cin}->64 @{B}x{H}x{W}: {rows} rows per image, max rel error vs the sum of the stored values {err:.2e}")
+    assert err < 2e-6
+    p = ops.SEParams(randn(4, 64, seed=95).cuda() * 0.2, randn(4, seed=96).cuda() * 0.1, randn(64, 4, seed=97).cuda() * 0.5, randn(64, seed=98).cuda() * 0.1, 64, 4)
+    g0, g1 = ops.se_gate(fused, p), ops.se_gate(fused, p, partial=sums[0])
+    assert float((g0 - g1).abs().max()) < 1e-6
+    # a conv whose kernel has no fused sum leaves the list empty (the caller falls back to tdvc_channel_sum)
+    none = []
+    ops.conv(to_fm(rnd16(randn(1, 64, 96, 96, seed=99)), ops), ops.pack_conv(rnd16(randn(64, 64, 3, 3, seed=100) * 0.04), None, stride=1, pad=1), chan_sum=none)
+    assert none == []
+
+
 N16_CASES = [
     # name, N, cin, cout, k, H, W: the few-output-channel layers at >= 8192 output pixels (conv_n16: 16-row MFMA tiles)
     ("n16_7x7_8_32", 1, 8, 32, 7, 90, 140),        # SPyNet basic module, first conv: two cout blocks, four taps per k-step
