@@ -37,33 +37,50 @@
 
 namespace {
 
-constexpr int PW = 30;                       // output columns per strip
-constexpr int ROWB = 5120;                   // ring row: 40 pixel slots x 128 B = 5 DMA pieces of 1 KB (34 used)
+// Two strip geometries (PairGeo<NCB>, NCB = 16-column blocks a wave computes per row):
+//   NCB = 2: 30 output columns per strip, 34-pixel ring rows (5 DMA pieces), 16-row input ring 8 rows ahead -- rounds 2 and 3;
+//   NCB = 4 (round 4): 62 output columns per strip, 66-pixel ring rows (9 pieces), 10-row input ring 4 rows ahead.  Per step and SIMD
+//            144 MFMAs (2 304 cycles) stand against the same barrier / first-fragment latency / pack overheads as 72 did (the measure that
+//            took conv_row past 0.50 of the peak), the column halo falls from 13 % to 6 %, and a 1920-column map is 31 strips
+//            (30 x 62 + 60).  The ring is as deep as 160 KB of LDS allow: 10 x 9 KB + t ring 4 x 9 KB + staging ring 4 x 8 KB = 158 KB.
 // ---- synchronisation geometry.  A "step" k consumes one input row; a workgroup barrier closes every BI-th step, so between
 // two barriers any two waves are at most BI - 1 steps apart and always in the same barrier interval.  Every ring / landing
 // condition the kernel relies on is one named inequality below (row numbers in step units: "row r" = what step r consumes).
 constexpr int BI = 2;                        // row steps per workgroup barrier (a power of two)
-constexpr int XRING = 16;                    // input ring rows (power of two)
-constexpr int PF = 8;                        // the DMA of row k + PF is ISSUED in step k (conv1 waves)
-constexpr int HD = 4;                        // land_wait() after step s lets the DMA issued in steps s - HD + 1 .. s stay in flight
-constexpr int VM_PER_STEP = 2;               // most vector-memory instructions a conv1 wave issues per step (its piece + piece 4)
 constexpr int TRING = 2 * BI;                // t ring rows: conv1 writes row k - 1 in step k, conv2 reads row k - 1 - BI
 constexpr int SRING = 2 * BI;                // staging ring rows: conv2 writes row k in step k, stores row k - BI
 constexpr int T_LAG = 1 + BI;                // conv2 consumes t row r in step r + T_LAG (r is written in step r + 1)
 constexpr int ID_LAG = 2 + BI;               // conv2 reads the identity (x ring row k - ID_LAG) in step k
-constexpr int X0 = 0, T0 = XRING * ROWB, S0 = T0 + TRING * ROWB, SROW = 4096;
-constexpr int LDS_PAIR = S0 + SRING * SROW;
-// (1) input ring, write-after-read.  The DMA issued in step k by the fastest conv1 wave overwrites row k + PF - XRING; the
-//     slowest wave of the interval is at step >= k - (BI - 1) and its oldest x-ring read is the identity row ID_LAG behind it:
-//     k + PF - XRING < k - (BI - 1) - ID_LAG.
-static_assert(PF - XRING < -(BI - 1) - ID_LAG, "input ring: a DMA would land on a row whose identity a conv2 wave BI - 1 steps behind has not read (needs PF + 2 BI + 2 <= XRING)");
-// (2) input ring, read-after-write (landing).  A wave's own pieces of row r (issued in step r - PF) are only known to have
-//     landed after its land_wait() of a step s >= r - PF + HD, and other waves' pieces only after a barrier behind that wait.
-//     The last barrier before step r closes a step kb >= r - BI: r - PF + HD <= r - BI.
-static_assert(PF >= HD + BI, "landing: row r must be past land_wait()'s history window before the last barrier in front of step r");
-// (3) the counted wait: at most HD steps x VM_PER_STEP instructions are left in flight, land_wait() has a case for every
-//     sum in [HD, HD * VM_PER_STEP] and falls back to vmcnt(0) otherwise; the hardware counter holds 63.
-static_assert(HD == 4 && VM_PER_STEP == 2 && HD * VM_PER_STEP <= 63, "land_wait(): the switch covers sums 4..8 of a 4-step history");
+template <int NCB> struct PairGeoBase;
+// XRING: input ring rows; PF: the DMA of row k + PF is ISSUED in step k (conv1 waves); HD: land_wait() after step s lets the DMA issued in
+// steps s - HD + 1 .. s stay in flight
+template <> struct PairGeoBase<2> { static constexpr int PIECES = 5, XRING = 16, PF = 8, HD = 4; };
+template <> struct PairGeoBase<4> { static constexpr int PIECES = 9, XRING = 10, PF = 4, HD = 2; };
+template <int NCB> struct PairGeo : PairGeoBase<NCB> {
+  using G = PairGeoBase<NCB>;
+  static constexpr int PW = 16 * NCB - 2;            // output columns per strip
+  static constexpr int NPX = PW + 4;                 // input pixels per ring row
+  static constexpr int ROWB = G::PIECES * 1024;      // ring row: 8 pixel slots of 128 B per 1-KB DMA piece
+  static constexpr int TROWB = ROWB;                 // t ring row: 16 NCB pixels used; conv2's two waste columns read two more (never stored)
+  static constexpr int SROW = 16 * NCB * 128;        // staging row
+  static constexpr int X0 = 0, T0 = G::XRING * ROWB, S0 = T0 + TRING * TROWB;
+  static constexpr int LDS = S0 + SRING * SROW;
+  static_assert(NPX * 128 <= ROWB, "ring row holds the strip's input pixels");
+  // (1) input ring, write-after-read.  The DMA issued in step k by the fastest conv1 wave overwrites row k + PF - XRING; the
+  //     slowest wave of the interval is at step >= k - (BI - 1) and its oldest x-ring read is the identity row ID_LAG behind it:
+  //     k + PF - XRING < k - (BI - 1) - ID_LAG.
+  static_assert(G::PF - G::XRING < -(BI - 1) - ID_LAG, "input ring: a DMA would land on a row whose identity a conv2 wave BI - 1 steps behind has not read (needs PF + 2 BI + 2 <= XRING)");
+  // (2) input ring, read-after-write (landing).  A wave's own pieces of row r (issued in step r - PF) are only known to have
+  //     landed after its land_wait() of a step s >= r - PF + HD, and other waves' pieces only after a barrier behind that wait.
+  //     The last barrier before step r closes a step kb >= r - BI: r - PF + HD <= r - BI.
+  static_assert(G::PF >= G::HD + BI, "landing: row r must be past land_wait()'s history window before the last barrier in front of step r");
+  // (3) the counted wait: conv1 waves issue nothing but DMA, a fixed number per step (NCB = 2: 1 + 1 + 1 + 2 over any four consecutive
+  //     steps; NCB = 4: 2 per step, wave 0 three), so HD steps of history are a constant the hardware counter (63) holds.
+  static_assert((NCB == 2 && G::HD == 4) || (NCB == 4 && G::HD == 2), "land_wait(): constant counts for these two histories");
+  // (6) the identity row k - ID_LAG was consumed by conv1 in step k - ID_LAG (so it has landed) and is still in the ring by (1).
+  static_assert(ID_LAG >= 1 && ID_LAG <= G::XRING - G::PF - BI, "identity row inside the input ring");
+  static_assert(LDS <= 160 * 1024, "rings inside 160 KB of LDS");
+};
 // (4) t ring.  In one barrier interval [m BI, m BI + BI - 1] conv1 writes rows m BI - 1 .. m BI + BI - 2 and conv2 reads rows
 //     m BI - T_LAG .. m BI + BI - 1 - T_LAG: 2 BI consecutive rows when T_LAG = 1 + BI, which must not alias; a row is read BI
 //     steps after it was written and overwritten BI steps after it was read: a barrier lies between either pair.
@@ -71,17 +88,22 @@ static_assert(T_LAG == 1 + BI && TRING >= 2 * BI && (TRING & (TRING - 1)) == 0, 
 // (5) staging ring: row k written in step k (each conv2 wave its 16 channels), stored by thread items in step k + BI,
 //     overwritten in step k + SRING: a barrier between write and store needs the BI lag, one between store and overwrite SRING - BI >= BI.
 static_assert(SRING >= 2 * BI && (SRING & (SRING - 1)) == 0, "staging ring: BI rows being written + BI rows being stored");
-// (6) the identity row k - ID_LAG was consumed by conv1 in step k - ID_LAG (so it has landed) and is still in the ring by (1).
-static_assert(ID_LAG >= 1 && ID_LAG <= XRING - PF - BI, "identity row inside the input ring");
-static_assert((BI & (BI - 1)) == 0 && (XRING & (XRING - 1)) == 0 && LDS_PAIR <= 160 * 1024, "power-of-two rings inside 160 KB of LDS");
+static_assert((BI & (BI - 1)) == 0, "power-of-two barrier interval");
 // BI = 4 (2.5 % faster in isolation) fails (1)+(2) with HD = 4: PF >= 8 and PF <= 6.  With HD = 2 / PF = 6 both hold and the
 // rings take 155 648 B; measured gain < 1 % on the frame's four-slice launches, so BI = 2 ships.
 constexpr int NTHR = 512;
 // round 4 (from conv_row.hip, tools/ab_row.py): a conv1 wave issues the next row's DMA pieces after the first third of its MFMAs instead
 // of in front of them -- at the top of a step both waves of a SIMD did their non-matrix work side by side in front of an idle matrix pipe --
-// and waits with a constant count: every conv1 wave issues 1 + 1 + 1 + 2 = 5 instructions over any four consecutive issuing steps
+// and waits with a constant count
 #ifndef PAIR_DMA_MID
 #define PAIR_DMA_MID 1
+#endif
+// NCB = 4: fragment groups in flight (this one + PAIR_FBN - 1 being read) and the group behind which a conv1 wave issues its DMA
+#ifndef PAIR_FBN
+#define PAIR_FBN 2
+#endif
+#ifndef PAIR_MID_G
+#define PAIR_MID_G 1
 #endif
 
 struct PairParams {
@@ -123,9 +145,19 @@ __device__ __forceinline__ half4 actk(half4 v, half4 sl) {
   }
 }
 
+// ring slot of row kk: a mask for the 16-row ring, a division by a constant for the 10-row ring -- on the scalar unit (kk is wave-uniform)
+template <int XRING> __device__ __forceinline__ int pair_slot(int kk) {
+  if constexpr ((XRING & (XRING - 1)) == 0) return kk & (XRING - 1);
+  else return __builtin_amdgcn_readfirstlane(kk) % XRING;
+}
+
 // A1 / A2: activation after conv1 / conv2: 0 none, 1 ReLU, 2 max(v, v * slope) (LeakyReLU; slope 1 = none)
-template <int A1, int A2, bool ADDX, bool RES2, bool STAMP = false>
+template <int NCB, int A1, int A2, bool ADDX, bool RES2, bool STAMP = false>
 __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, long long* stamps = nullptr, int stamp_cap = 0) {
+  using G = PairGeo<NCB>;
+  constexpr int PW = G::PW, ROWB = G::ROWB, TROWB = G::TROWB, SROW = G::SROW, XRING = G::XRING, PF = G::PF, X0 = G::X0, T0 = G::T0, S0 = G::S0;
+  constexpr int NF = 6 * NCB;                  // B fragments of a row
+  constexpr int NIT = NCB / 2;                 // 16-byte store items per conv2 thread and row (256 threads, 8 items per pixel)
   long long st_busy = 0, st_vm = 0, st_bar = 0, st_n = 0;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
@@ -141,31 +173,34 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
   const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + 64 * grp + 16 * wq + 4 * kb);   // C/D rows 4 kb + i of this wave's block
 
   // ---- per-lane LDS offsets inside a ring row
-  int foff[3][2];                              // B fragment (dx, channel chunk) of column block 0: pixel dx + (l & 15); block 1 sits
-#pragma unroll                                 // 16 pixels = 2048 B further (16 pixels do not change the swizzle term)
+  int foff[3][2];                              // B fragment (dx, channel chunk) of column block 0: pixel dx + (l & 15); block cb sits
+#pragma unroll                                 // 16 cb pixels = 2048 cb B further (16 pixels do not change the swizzle term)
   for (int dx = 0; dx < 3; ++dx) {
     const int q = dx + r16, sw = swz(q);
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) foff[dx][kc] = q * 128 + (((4 * kc + kb) ^ sw) << 4);
   }
-  int doff[2], roff[2];                        // C/D layout (pixel l & 15, channels 16 wq + 4 kb ..+3): t / staging write, identity read
-#pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
-    const int q = 16 * cb + r16, c = 2 * wq + (kb >> 1);
-    doff[cb] = q * 128 + ((c ^ swz(q)) << 4) + 8 * (kb & 1);
-    const int qx = q + 2;                      // output column yi sits at input pixel yi + 2
-    roff[cb] = qx * 128 + ((c ^ swz(qx)) << 4) + 8 * (kb & 1);
-  }
+  // C/D layout (pixel l & 15, channels 16 wq + 4 kb ..+3) of column block 0: t / staging write, identity read (output column yi sits at
+  // input pixel yi + 2); block cb again 2048 cb B further
+  const int cdc = 2 * wq + (kb >> 1);
+  const int doff = r16 * 128 + ((cdc ^ swz(r16)) << 4) + 8 * (kb & 1);
+  const int roff = (r16 + 2) * 128 + ((cdc ^ swz(r16 + 2)) << 4) + 8 * (kb & 1);
   // DMA items (conv1 waves): piece j of a row covers pixels 8 j .. 8 j + 7 (lane: slot lane & 7 of pixel 8 j + (lane >> 3)).
-  // Every step wave wq sends piece wq of the row 8 steps ahead; piece 4 (pixels 32, 33) goes round the four waves
-  int soff_own, soff_4;
+  // NCB = 2: every step wave wq sends piece wq of the row PF steps ahead; piece 4 (pixels 32, 33) goes round the four waves.
+  // NCB = 4: wave wq sends pieces wq and wq + 4, wave 0 also piece 8 (pixels 64, 65).
+  constexpr int PLAST = G::PIECES - 1;         // the odd piece
+  int soff_own, soff_hi = 0, soff_last;
   {
     const int q = 8 * wq + (lane >> 3), c = (lane & 7) ^ swz(q);
     soff_own = q * p.x_sp + c * 8;
-    const int q4 = 32 + (lane >> 3), c4 = (lane & 7) ^ swz(q4);
-    soff_4 = q4 * p.x_sp + c4 * 8;
+    if constexpr (NCB == 4) {
+      const int qh = 32 + q, ch = (lane & 7) ^ swz(qh);
+      soff_hi = qh * p.x_sp + ch * 8;
+    }
+    const int ql = 8 * PLAST + (lane >> 3), cl = (lane & 7) ^ swz(ql);
+    soff_last = ql * p.x_sp + cl * 8;
   }
-  // store item (conv2 waves): thread = (output column t >> 3, slot t & 7), t = tid - 256
+  // store items (conv2 waves): item u of thread t = tid - 256 is (output column (t >> 3) + 32 u, slot t & 7)
   const int s_t = tid & 255;
   const int s_yi = s_t >> 3, s_c = (s_t & 7) ^ swz(s_yi);
 
@@ -185,9 +220,15 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
   // activations as max(v, v * slope) in packed fp16 (slope 1: none, 0: ReLU), what the two-launch path computes
   const half_t hs1 = (half_t)p.slope1, hs2 = (half_t)p.slope2;
   const half4 sl1 = {hs1, hs1, hs1, hs1}, sl2 = {hs2, hs2, hs2, hs2};
-  f32x4 acc[3][2];                             // rotating accumulator rows (of t in group 0, of y in group 1)
-  half8 fb[12];                                // B fragments of the row being consumed
-  half8 r2v = {};
+  // The two roles are instantiated as the two branches of ONE wave-uniform `if` around the whole job loop: written as `if (grp == 0)`
+  // inside a step, every per-lane value of either role (DMA source offsets and column flags, store items and residual rows) stays live
+  // in both -- 20 to 60 spilled registers in the NCB = 4 kernel, and a spill is a scratch access the counted vmcnt knows nothing of.
+  // Both roles execute the same sequence of barriers.
+  auto run = [&](auto ROLEc) __attribute__((always_inline)) {
+  constexpr int ROLE = decltype(ROLEc)::value;       // 0: conv1 wave, 1: conv2 wave
+  f32x4 acc[3][NCB];                           // rotating accumulator rows (of t in group 0, of y in group 1)
+  half8 fb[NF];                                // B fragments of the row being consumed
+  half8 r2v[NIT] = {};
 
   for (int job = jfirst; job < jend; job += jstep) {
     const int n = job / (p.strips * p.segs);
@@ -198,37 +239,41 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
     const half_t* xn = p.x + (long)n * p.x_sn;
     half_t* yn = p.y + (long)n * p.y_sn;
 
-    bool col_own, col_4;                       // this lane's pixel of its pieces is inside the image (and one of the 34)
+    bool col_own, col_hi = false, col_last;    // this lane's pixel of its pieces is inside the image (and one of the strip's)
     {
-      const int q = 8 * wq + (lane >> 3), q4 = 32 + (lane >> 3);
+      const int q = 8 * wq + (lane >> 3), ql = 8 * PLAST + (lane >> 3);
       col_own = c0 - 2 + q >= 0 && c0 - 2 + q < p.W;
-      col_4 = q4 < 34 && c0 - 2 + q4 < p.W;
+      if constexpr (NCB == 4) col_hi = c0 - 2 + 32 + q < p.W;
+      col_last = ql < G::NPX && c0 - 2 + ql < p.W;
     }
     // t columns outside the image are the zero padding of conv2
-    unsigned tmask[2];
+    unsigned tmask[NCB];
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
+    for (int cb = 0; cb < NCB; ++cb) {
       const int col = c0 - 1 + 16 * cb + r16;
       tmask[cb] = (col >= 0 && col < p.W) ? 0xFFFFFFFFu : 0u;
     }
-    const bool s_ok = s_yi < PW && c0 + s_yi < p.W && !(p.experiment & 2);
+    bool s_ok[NIT];
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) s_ok[u] = s_yi + 32 * u < PW && c0 + s_yi + 32 * u < p.W && !(p.experiment & 2);
     // rows above the segment never finish a valid chain; start them from zero rather than from whatever the registers hold
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3)
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) acc[s3][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int cb = 0; cb < NCB; ++cb) acc[s3][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // x row ra - 2 + kk into ring slot kk & 15: this wave's piece, plus piece 4 when it is this wave's turn; returns the
-    // number of DMA instructions issued (conv1 waves only)
+    // x row ra - 2 + kk into its ring slot: this wave's pieces (conv1 waves only); returns whether anything was issued
     auto issue_row = [&](int kk) __attribute__((always_inline)) -> int {
       const int row = ra - 2 + kk;
       const bool rowok = row >= 0 && row < p.H;
       const half_t* base = xn + ((long)row * p.W + (c0 - 2)) * p.x_sp;
-      const unsigned dst = lds0 + X0 + (kk & (XRING - 1)) * ROWB;
+      const unsigned dst = lds0 + X0 + pair_slot<XRING>(kk) * ROWB;
       glds16((rowok && col_own) ? base + soff_own : p.zeros, dst + wq * 1024);
-      if (wq == (kk & 3)) {
-        glds16((rowok && col_4) ? base + soff_4 : p.zeros, dst + 4 * 1024);
-        return 2;
+      if constexpr (NCB == 4) {
+        glds16((rowok && col_hi) ? base + soff_hi : p.zeros, dst + (wq + 4) * 1024);
+        if (wq == 0) glds16((rowok && col_last) ? base + soff_last : p.zeros, dst + PLAST * 1024);
+      } else {
+        if (wq == (kk & 3)) glds16((rowok && col_last) ? base + soff_last : p.zeros, dst + PLAST * 1024);
       }
       return 1;
     };
@@ -239,34 +284,67 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
         for (int kc = 0; kc < 2; ++kc) {
           const unsigned char* b0 = smem + (rowbase + foff[dx][kc]);      // one address per (dx, kc); the column block is an
 #pragma unroll                                                           // immediate offset of the read
-          for (int cb = 0; cb < 2; ++cb) fb[(cb * 3 + dx) * 2 + kc] = *reinterpret_cast<const half8*>(b0 + cb * 2048);
+          for (int cb = 0; cb < NCB; ++cb) fb[(cb * 3 + dx) * 2 + kc] = *reinterpret_cast<const half8*>(b0 + cb * 2048);
         }
     };
-    // the 36 MFMAs of one row: fragment (cb, dx, kc) x taps (dy, dx); SN / SM / SD: accumulator rows that start here (dy 0,
-    // bias as the C operand), continue (dy 1) and finish (dy 2, issued first so that the pack of the finished row overlaps the rest)
-    auto row_mfmas = [&](auto SNc, auto SMc, auto SDc, auto fin, auto mid) __attribute__((always_inline)) {
+    // the 18 NCB MFMAs of one row: fragment (cb, dx, kc) x taps (dy, dx); SN / SM / SD: accumulator rows that start here (dy 0,
+    // bias as the C operand), continue (dy 1) and finish (dy 2).
+    // NCB = 2: all 12 fragments are read up front; dy 2 is issued first so that the pack of the finished row (fin) overlaps the rest.
+    // NCB = 4: 24 fragments next to 72 weight and 48 accumulator registers do not fit (65-100 registers spilled): the row goes by fragment
+    //          GROUP (dx, kc) -- four fragments, 12 MFMAs -- with the next group's reads in flight under this group's MFMAs; the finished
+    //          row is packed behind the last group.  Each accumulator still receives its (dx, kc) terms in the same order: the sums are
+    //          bit-identical to the NCB = 2 kernel's.
+    auto row_mfmas = [&](unsigned rowbase, auto SNc, auto SMc, auto SDc, auto fin, auto mid) __attribute__((always_inline)) {
       constexpr int SN = decltype(SNc)::value, SM = decltype(SMc)::value, SD = decltype(SDc)::value;
+      if constexpr (NCB == 4) {
+        half8 fg[PAIR_FBN][NCB];
+        auto loadg = [&](int g, half8 (&dst)[NCB]) __attribute__((always_inline)) {
+          const unsigned char* b0 = smem + (rowbase + foff[g >> 1][g & 1]);
 #pragma unroll
-      for (int dyo = 0; dyo < 3; ++dyo) {
-        const int dy = 2 - dyo;
+          for (int cb = 0; cb < NCB; ++cb) dst[cb] = *reinterpret_cast<const half8*>(b0 + cb * 2048);
+        };
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
+        for (int g = 0; g < PAIR_FBN - 1; ++g) loadg(g, fg[g]);
 #pragma unroll
-          for (int kc = 0; kc < 2; ++kc)
+        for (int g = 0; g < 6; ++g) {
+          const int dx = g >> 1, kc = g & 1;
+          if (g + PAIR_FBN - 1 < 6) loadg(g + PAIR_FBN - 1, fg[(g + PAIR_FBN - 1) % PAIR_FBN]);
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-              const int slot = dy == 2 ? SD : (dy == 1 ? SM : SN);
-              const bool first = dy == 0 && dx == 0 && kc == 0;
-              acc[slot][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[(dy * 3 + dx) * 2 + kc], fb[(cb * 3 + dx) * 2 + kc],
-                                                                     first ? bias4 : acc[slot][cb], 0, 0, 0);
-            }
-        if (dy == 2) fin();
-        if (dyo == 0) mid();
+          for (int dyo = 0; dyo < 3; ++dyo) {
+            const int dy = 2 - dyo;
+            const int slot = dy == 2 ? SD : (dy == 1 ? SM : SN);
+            const bool first = dy == 0 && g == 0;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+              acc[slot][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[(dy * 3 + dx) * 2 + kc], fg[g % PAIR_FBN][cb], first ? bias4 : acc[slot][cb], 0, 0, 0);
+          }
+          if (g == PAIR_MID_G) mid();
+        }
+        fin();
+      } else {
+        load_frags(rowbase);
+#pragma unroll
+        for (int dyo = 0; dyo < 3; ++dyo) {
+          const int dy = 2 - dyo;
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+              for (int cb = 0; cb < NCB; ++cb) {
+                const int slot = dy == 2 ? SD : (dy == 1 ? SM : SN);
+                const bool first = dy == 0 && dx == 0 && kc == 0;
+                acc[slot][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[(dy * 3 + dx) * 2 + kc], fb[(cb * 3 + dx) * 2 + kc],
+                                                                       first ? bias4 : acc[slot][cb], 0, 0, 0);
+              }
+          if (dy == 2) fin();
+          if (dyo == 0) mid();
+        }
       }
     };
 
     // ---- prologue: the first PF rows; everything landed and visible before step 0
-    if (grp == 0) {
+    if constexpr (ROLE == 0) {
 #pragma unroll
       for (int kk = 0; kk < PF; ++kk)
         if (kk <= rows + 3) issue_row(kk);
@@ -275,26 +353,14 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
     pair_barrier();
 
     const int K = (rows + 4 + 2 * BI + BI - 1) & ~(BI - 1);      // row steps, a whole number of barrier intervals
-    unsigned hist = 0;                         // vector-memory operations this wave issued in each of the last four steps (one byte each)
-    // Before a step's barrier: everything this wave sent more than four steps ago has landed (row k + 4 is read from step
-    // k + 4 on); the operations of the last four steps -- their number is tracked exactly -- may stay in flight.  Vector
-    // memory operations of a wave complete in order on this architecture (one counter for loads, stores and LDS-DMA).
+    // Before a step's barrier: everything this wave sent more than HD steps ago has landed (NCB = 2: row k + 4 is read from step
+    // k + 4 on); the DMA of the last HD steps -- a constant number: conv1 waves issue no other vector-memory operation -- may stay in
+    // flight.  Vector memory operations of a wave complete in order on this architecture (one counter for loads, stores and LDS-DMA).
     auto land_wait = [&](int nvm) __attribute__((always_inline)) {
-#if PAIR_DMA_MID
-      if (nvm) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // shorter histories (first steps) have fewer in flight: no wait, nothing older to wait for
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // issuing has stopped (segment tail)
-      return;
-#endif
-      hist = (hist << 8) | (unsigned)nvm;
-      const unsigned sum = (hist & 0xFFu) + ((hist >> 8) & 0xFFu) + ((hist >> 16) & 0xFFu) + (hist >> 24);
-      switch (sum) {
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-      }
+      if (!nvm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // issuing has stopped (segment tail)
+      else if constexpr (NCB == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // 1 + 1 + 1 + 2 over any four issuing steps; shorter histories (first steps) have fewer in flight
+      else if (wq == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                  // two steps x three pieces
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                               // two steps x two pieces
     };
     // One row step k.  conv1 waves consume x row i = ra - 2 + k: t rows i + 1 (started), i, i - 1 (finished, into the t ring).
     // conv2 waves consume t row i - 1 - BI: y rows i - BI (started), i - 1 - BI, i - 2 - BI (finished, + identity, into a staging
@@ -312,19 +378,17 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
       const int i = ra - 2 + k;
       long long t0 = 0, t1 = 0, t2 = 0;
       if constexpr (STAMP && FULL) t0 = clock64();       // lgkmcnt is 0 here (pair_barrier): the read costs nothing
-      if (grp == 0) {
+      if constexpr (ROLE == 0) {
         // ---- conv1 wave: t row new = slot (PH + 1) % 3, mid = PH, done = (PH + 2) % 3
         int nvm = 0;
         if (FULL || k <= rows + 3) {
-          load_frags(X0 + (k & (XRING - 1)) * ROWB);
-          if (!PAIR_DMA_MID && k + PF <= rows + 3 && !(p.experiment & 1)) nvm = issue_row(k + PF);
-          row_mfmas(S1c{}, S0c{}, S2c{}, [&]() __attribute__((always_inline)) {
+          row_mfmas(X0 + pair_slot<XRING>(k) * ROWB, S1c{}, S0c{}, S2c{}, [&]() __attribute__((always_inline)) {
             // t row i - 1 -> fp16, activation, zero outside the image, into the t ring
             const int trow = i - 1;
             const unsigned rowm = (trow >= 0 && trow < p.H) ? 0xFFFFFFFFu : 0u;
-            unsigned char* tb = smem + T0 + ((k - 1) & (TRING - 1)) * ROWB;
+            unsigned char* tb = smem + T0 + ((k - 1) & (TRING - 1)) * TROWB + doff;
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
+            for (int cb = 0; cb < NCB; ++cb) {
               const f32x4 v = acc[(PH + 2) % 3][cb];
               half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
               h = actk<A1>(h, sl1);
@@ -332,10 +396,10 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
               u32x2 u = __builtin_bit_cast(u32x2, h);
               const unsigned m = rowm & tmask[cb];
               u[0] &= m; u[1] &= m;
-              *reinterpret_cast<u32x2*>(tb + doff[cb]) = u;
+              *reinterpret_cast<u32x2*>(tb + cb * 2048) = u;
             }
           }, [&]() __attribute__((always_inline)) {
-            if (PAIR_DMA_MID && k + PF <= rows + 3 && !(p.experiment & 1)) nvm = issue_row(k + PF);
+            if (k + PF <= rows + 3 && !(p.experiment & 1)) nvm = issue_row(k + PF);
           });
         }
         if constexpr (STAMP && FULL) {
@@ -347,30 +411,36 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
         // ---- conv2 wave: new = (PH + 2) % 3, mid = (PH + 1) % 3, done = PH
         const int srow = ra + k - 4 - 2 * BI;  // the y row finished BI row steps ago (before the last barrier): staging row -> memory
         if (FULL || (srow >= ra && srow < rb)) {
-          half8 yv = *reinterpret_cast<const half8*>(smem + S0 + ((k - BI) & (SRING - 1)) * SROW + s_t * 16);
-          if constexpr (RES2) yv = yv + r2v;
-          half_t* dst = s_ok ? yn + ((long)srow * p.W + c0 + s_yi) * p.y_sp + s_c * 8 : p.dump + s_t * 8;
-          *reinterpret_cast<half8*>(dst) = yv;
+#pragma unroll
+          for (int u = 0; u < NIT; ++u) {
+            half8 yv = *reinterpret_cast<const half8*>(smem + S0 + ((k - BI) & (SRING - 1)) * SROW + (s_t + 256 * u) * 16);
+            if constexpr (RES2) yv = yv + r2v[u];
+            half_t* dst = s_ok[u] ? yn + ((long)srow * p.W + c0 + s_yi + 32 * u) * p.y_sp + s_c * 8 : p.dump + (s_t + 256 * u) * 8;
+            *reinterpret_cast<half8*>(dst) = yv;
+          }
         }
         if constexpr (RES2) {
           const int nrow = srow + 1;
-          const bool ok = s_ok && (FULL || (nrow >= ra && nrow < rb));
-          const half_t* src = ok ? p.res2 + (long)n * p.r2_sn + ((long)nrow * p.W + c0 + s_yi) * p.r2_sp + s_c * 8 : p.zeros;
-          r2v = *reinterpret_cast<const half8*>(src);
+#pragma unroll
+          for (int u = 0; u < NIT; ++u) {
+            const bool ok = s_ok[u] && (FULL || (nrow >= ra && nrow < rb));
+            const half_t* src = ok ? p.res2 + (long)n * p.r2_sn + ((long)nrow * p.W + c0 + s_yi + 32 * u) * p.r2_sp + s_c * 8 : p.zeros;
+            r2v[u] = *reinterpret_cast<const half8*>(src);
+          }
         }
         if (FULL || (k >= BI + 2 && k <= rows + 3 + BI)) {
-          load_frags(T0 + ((k - T_LAG) & (TRING - 1)) * ROWB);       // t row i - 1 - BI, finished before the last barrier
-          row_mfmas(S2c{}, S1c{}, S0c{}, [&]() __attribute__((always_inline)) {
+          // t row i - 1 - BI, finished before the last barrier
+          row_mfmas(T0 + ((k - T_LAG) & (TRING - 1)) * TROWB, S2c{}, S1c{}, S0c{}, [&]() __attribute__((always_inline)) {
             // y row i - 2 - BI -> fp16, activation, + identity (that x row is still in the ring), into the staging row
-            unsigned char* sb = smem + S0 + (k & (SRING - 1)) * SROW;
-            const unsigned char* xb = smem + X0 + ((k - ID_LAG) & (XRING - 1)) * ROWB;
+            unsigned char* sb = smem + S0 + (k & (SRING - 1)) * SROW + doff;
+            const unsigned char* xb = smem + X0 + pair_slot<XRING>(k - ID_LAG) * ROWB + roff;
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
+            for (int cb = 0; cb < NCB; ++cb) {
               const f32x4 v = acc[PH][cb];
               half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
               h = actk<A2>(h, sl2);
-              if constexpr (ADDX) h = h + *reinterpret_cast<const half4*>(xb + roff[cb]);
-              *reinterpret_cast<half4*>(sb + doff[cb]) = h;
+              if constexpr (ADDX) h = h + *reinterpret_cast<const half4*>(xb + cb * 2048);
+              *reinterpret_cast<half4*>(sb + cb * 2048) = h;
             }
           }, []() {});
         }
@@ -406,6 +476,9 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
     }
     edge_steps(k, K);
   }
+  };
+  if (grp == 0) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
   if constexpr (STAMP) {
     if (lane == 0 && (int)blockIdx.x < stamp_cap) {
       long long* o = stamps + ((long)blockIdx.x * 8 + wave) * 8;
@@ -418,11 +491,14 @@ __global__ __launch_bounds__(NTHR, 1) void conv_pair_kernel(const PairParams p, 
 
 static bool g_pair_enabled = true;
 static int g_pair_experiment = 0;
+static int g_pair_geometry = 0;
 static long long* g_pair_stamps = nullptr;
 static int g_pair_stamp_cap = 0;
 // diagnostics: [workgroup][wave][8] int64 = {busy, vmcnt wait, barrier wait, conv1 phase, steps} cycle sums over the steady-state steps
 extern "C" void tdvc_debug_set_stamp_buffer_pair(void* buf, int cap_blocks) { g_pair_stamps = (long long*)buf; g_pair_stamp_cap = cap_blocks; }
 extern "C" void tdvc_debug_set_pair_experiment(int e) { g_pair_experiment = e; }
+// tests and A/B benchmarks: 2 / 4 = 30- / 62-column strips for every launch, 0 = chosen per width
+extern "C" void tdvc_debug_set_pair_geometry(int ncb) { g_pair_geometry = ncb; }
 // tests and A/B benchmarks: 0 makes tdvc_conv_pair_supported() answer no (callers then run the two convs separately)
 extern "C" void tdvc_debug_enable_conv_pair(int enable) { g_pair_enabled = enable != 0; }
 
@@ -498,7 +574,12 @@ extern "C" int tdvc_conv_pair(const tdvc_conv_pair_desc* d, void* stream) {
   p.N = d->x.N; p.H = d->x.H; p.W = d->x.W;
   p.slope1 = slope_of(d->act1, d->slope1);
   p.slope2 = slope_of(d->act2, d->slope2);
-  p.strips = (p.W + PW - 1) / PW;
+  // strip geometry: 62-column strips (NCB = 4) unless the narrow ones waste clearly fewer columns on this width (the wide steps are
+  // worth ~1.12x: tools/bench_pair.py); tdvc_debug_set_pair_geometry() forces one
+  auto waste = [&](int pw) { return (double)(((p.W + pw - 1) / pw) * (pw + 2)) / (double)p.W; };
+  const int ncb = g_pair_geometry == 2 || g_pair_geometry == 4 ? g_pair_geometry : (waste(62) <= 1.12 * waste(30) ? 4 : 2);
+  const int PWsel = 16 * ncb - 2;
+  p.strips = (p.W + PWsel - 1) / PWsel;
   // row segments: fill 256 workgroups evenly; a segment pays 5 extra steps for its vertical halo
   const long base = (long)p.N * p.strips;
   int best = 1;
@@ -513,26 +594,30 @@ extern "C" int tdvc_conv_pair(const tdvc_conv_pair_desc* d, void* stream) {
   p.segs = (p.H + p.seg_rows - 1) / p.seg_rows;
   p.jobs = (int)(base * p.segs);
   const int grid = p.jobs < 256 ? p.jobs : 256;
-  auto go = [&](auto kern) -> int {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_PAIR);
+  auto go = [&](auto kern, int lds) -> int {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (err != hipSuccess) { tdvc_set_error("tdvc_conv_pair: hipFuncSetAttribute failed: %s", hipGetErrorString(err)); return (int)err; }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), LDS_PAIR, reinterpret_cast<hipStream_t>(stream), p, g_pair_stamps, g_pair_stamp_cap);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, reinterpret_cast<hipStream_t>(stream), p, g_pair_stamps, g_pair_stamp_cap);
     return 0;
   };
   // specialised: ReLU / none (Res_Block); everything else through the slope form
   const bool resblock = d->act1 == TDVC_ACT_RELU && d->act2 == TDVC_ACT_NONE;
   const int sel = (resblock ? 4 : 0) + (d->add_input ? 2 : 0) + (d->res2.p ? 1 : 0);
-  int rc;
-  switch (sel) {
-    case 0: rc = go(&conv_pair_kernel<2, 2, false, false>); break;
-    case 1: rc = go(&conv_pair_kernel<2, 2, false, true>); break;
-    case 2: rc = go(&conv_pair_kernel<2, 2, true, false>); break;
-    case 3: rc = go(&conv_pair_kernel<2, 2, true, true>); break;
-    case 4: rc = go(&conv_pair_kernel<1, 0, false, false>); break;
-    case 5: rc = go(&conv_pair_kernel<1, 0, false, true>); break;
-    case 6: rc = g_pair_stamps ? go(&conv_pair_kernel<1, 0, true, false, true>) : go(&conv_pair_kernel<1, 0, true, false>); break;
-    default: rc = go(&conv_pair_kernel<1, 0, true, true>); break;
-  }
+  auto launch = [&](auto ncbc) -> int {
+    constexpr int NCB = decltype(ncbc)::value;
+    constexpr int lds = PairGeo<NCB>::LDS;
+    switch (sel) {
+      case 0: return go(&conv_pair_kernel<NCB, 2, 2, false, false>, lds);
+      case 1: return go(&conv_pair_kernel<NCB, 2, 2, false, true>, lds);
+      case 2: return go(&conv_pair_kernel<NCB, 2, 2, true, false>, lds);
+      case 3: return go(&conv_pair_kernel<NCB, 2, 2, true, true>, lds);
+      case 4: return go(&conv_pair_kernel<NCB, 1, 0, false, false>, lds);
+      case 5: return go(&conv_pair_kernel<NCB, 1, 0, false, true>, lds);
+      case 6: return g_pair_stamps ? go(&conv_pair_kernel<NCB, 1, 0, true, false, true>, lds) : go(&conv_pair_kernel<NCB, 1, 0, true, false>, lds);
+      default: return go(&conv_pair_kernel<NCB, 1, 0, true, true>, lds);
+    }
+  };
+  const int rc = ncb == 4 ? launch(std::integral_constant<int, 4>{}) : launch(std::integral_constant<int, 2>{});
   if (rc) return rc;
   return tdvc_launch_status("tdvc_conv_pair");
 }

@@ -16,6 +16,19 @@ def _ops():
     return ops
 
 
+@pytest.fixture(params=[2, 4], ids=["strips30", "strips62"])
+def geom(request):
+    """both strip geometries of the kernel (conv_pair.hip, PairGeo<NCB>) instead of the per-width choice"""
+    import ctypes
+
+    from tdvc_amd import _lib
+    fn = _lib.lib().tdvc_debug_set_pair_geometry
+    fn.argtypes, fn.restype = [ctypes.c_int], None
+    fn(request.param)
+    yield request.param
+    fn(0)
+
+
 def _weights(seed):
     w1 = rnd16(randn(64, 64, 3, 3, seed=seed) * 0.05)
     w2 = rnd16(randn(64, 64, 3, 3, seed=seed + 1) * 0.05)
@@ -65,7 +78,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("N,H,W,act1,act2,add,with_res2,views", CASES)
-def test_conv_pair_vs_reference(N, H, W, act1, act2, add, with_res2, views, report):
+def test_conv_pair_vs_reference(N, H, W, act1, act2, add, with_res2, views, geom, report):
     ops = _ops()
     w1, b1, w2, b2 = _weights(11)
     x = rnd16(randn(N, 64, H, W, seed=21))
@@ -102,7 +115,7 @@ def test_conv_pair_vs_reference(N, H, W, act1, act2, add, with_res2, views, repo
         assert torch.equal(y.t, first), "launch-to-launch mismatch"
 
 
-def test_conv_pair_random_shapes(report):
+def test_conv_pair_random_shapes(geom, report):
     """seeded sweep over geometries, activations and residual options against the same pair as two tdvc_conv2d launches
     (strips / segments / multi-job walks are all functions of N, H, W)"""
     import random
@@ -133,7 +146,7 @@ def test_conv_pair_random_shapes(report):
 
 
 @pytest.mark.parametrize("N,H,W,r2", [(1, 33, 250, True), (4, 48, 192, True), (1, 100, 131, False)])
-def test_conv_pair_launches_are_reproducible(N, H, W, r2, report):
+def test_conv_pair_launches_are_reproducible(N, H, W, r2, geom, report):
     """150 launches of the shapes most exposed to a synchronisation hole (short row segments, a ragged last strip, the second
     residual slowing the conv2 waves) must all equal the first: with one barrier per FOUR row steps and a 16-row input ring
     the 33x250 case lost a write-after-read race on every few launches (tools/stress_pair.py; conv_pair.hip, `BI`)"""
@@ -147,6 +160,33 @@ def test_conv_pair_launches_are_reproducible(N, H, W, r2, report):
     bad = sum(0 if torch.equal(ops.conv_pair(x, pp, **kw).t, first) else 1 for _ in range(150))
     report(f"conv_pair {N}x{H}x{W} res2={r2}: {bad} of 150 launches differ from the first")
     assert bad == 0
+
+
+@pytest.mark.parametrize("N,H,W", [(1, 100, 131), (2, 64, 160), (1, 33, 250), (1, 136, 240)])
+def test_conv_pair_strip_geometries_bit_equal(N, H, W, report):
+    """30- and 62-column strips feed every accumulator its (tap, channel chunk) terms in the same order: the two kernels agree bit for bit
+    (ragged last strips, both residual forms, LeakyReLU pair)"""
+    import ctypes
+
+    from tdvc_amd import _lib
+    ops = _ops()
+    fn = _lib.lib().tdvc_debug_set_pair_geometry
+    fn.argtypes, fn.restype = [ctypes.c_int], None
+    w1, b1, w2, b2 = _weights(61)
+    pp = ops.pack_conv_pair(w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda())
+    x = to_fm(rnd16(randn(N, 64, H, W, seed=62)), ops)
+    r2 = to_fm(rnd16(randn(N, 64, H, W, seed=63)), ops)
+    try:
+        for kw in (dict(act1=ops.ACT_RELU, add_input=True), dict(act1=ops.ACT_LRELU, slope1=0.1, act2=ops.ACT_LRELU, slope2=0.1, add_input=False, res2=r2),
+                   dict(act1=ops.ACT_RELU, add_input=True, res2=r2)):
+            outs = []
+            for g in (2, 4):
+                fn(g)
+                outs.append(ops.conv_pair(x, pp, **kw).t.clone())
+            assert torch.equal(outs[0], outs[1]), kw
+    finally:
+        fn(0)
+    report(f"conv_pair {N}x{H}x{W}: 30- and 62-column strips bit-equal on three epilogue forms")
 
 
 def test_conv_pair_refuses_training_and_bad_shapes():

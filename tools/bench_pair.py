@@ -47,6 +47,19 @@ if os.environ.get("PAIR_EXPERIMENTS"):
         print(f"experiment {e}: {timed(lambda: ops.conv_pair(x, pp, out=y)):.1f} us", flush=True)
     fn(0)
 pair = lambda: ops.conv_pair(x, pp, out=y)
+if os.environ.get("PAIR_GEOMETRIES", "1") == "1":          # 30- against 62-column strips (conv_pair.hip, PairGeo<NCB>), interleaved
+    gfn = ops.L.lib().tdvc_debug_set_pair_geometry
+    gfn.argtypes, gfn.restype = [ctypes.c_int], None
+    res = {2: [], 4: []}
+    timed(pair)
+    for _ in range(4):
+        for g_ in (2, 4):
+            gfn(g_)
+            res[g_].append(timed(pair))
+    gfn(0)
+    for g_, v in res.items():
+        m = sorted(v)[len(v) // 2]
+        print(f"{N}x{H}x{W}: {16 * g_ - 2}-column strips {m:.1f} us (runs {[round(u, 1) for u in v]}) = {fl / m / 1e6:.0f} TFLOP/s ({fl / m / 1e6 / 2500:.3f} of peak)", flush=True)
 timed(pair); timed(two)                       # the first timed loop of a process runs ~20 % slow (clocks): not reported
 A, B = [], []
 for _ in range(4):
