@@ -36,6 +36,16 @@ static inline int tdvc_launch_status(const char* what) {
 }
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+// "done once" flags of per-DEVICE state (hipFuncSetAttribute applies to the current device only): one bool per device index; a
+// process that drives a second GPU sets the attribute there too.  Racing first launches on two threads set it twice: harmless.
+struct TdvcPerDeviceFlag {
+  bool done[64] = {};
+  bool& flag() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    return done[dev];
+  }
+};
 
 // device-side view of a tdvc_fmap
 struct FMap {

@@ -87,8 +87,8 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvParams p, const
   // load / matrix -- left to itself hipcc sank the loads behind `ok ? x : 0` branches (round 2) or regrouped the two sets so
   // that every k-step waited vmcnt(0) for the loads it had just issued (first round-3 build): 0.5 of the fp32 matrix peak.
   f32x4 a[2][MT][2], b[2][NT][2];
-  float bm[2][NT];
-  auto fetch = [&](int g, f32x4 (&af)[MT][2], f32x4 (&bf)[NT][2], float (&mk)[NT]) {
+  unsigned bm[2][NT];
+  auto fetch = [&](int g, f32x4 (&af)[MT][2], f32x4 (&bf)[NT][2], unsigned (&mk)[NT]) {
     const int gc = min(g, T - 1);
     const int ch = gc / p.steps, s = gc - ch * p.steps;
     int tap, cofs;
@@ -115,14 +115,14 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvParams p, const
       const float* bp = xn[nt] + ((long)iyc * p.W + ixc) * p.x_sp + cc;
       bf[nt][0] = *reinterpret_cast<const f32x4*>(bp);
       bf[nt][1] = *reinterpret_cast<const f32x4*>(bp + 4);
-      // out-of-image taps are zeroed by an OPAQUE multiplier, not by a select (x * 1.0f is exact; the clamped address always
-      // holds a finite in-image value)
-      float m = ok ? 1.f : 0.f;
+      // out-of-image taps are zeroed by an OPAQUE bit mask, not by a select (a select made hipcc sink the loads behind branches) and
+      // not by a multiply (Inf * 0 at a clamped border address would be NaN): exact zeros for any input
+      unsigned m = ok ? 0xFFFFFFFFu : 0u;
       asm volatile("" : "+v"(m));
       mk[nt] = m;
     }
   };
-  auto mfmas = [&](f32x4 (&af)[MT][2], f32x4 (&bf)[NT][2], float (&mk)[NT]) {
+  auto mfmas = [&](f32x4 (&af)[MT][2], f32x4 (&bf)[NT][2], unsigned (&mk)[NT]) {
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvParams p, const
         float bv[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          bv[nt] = bf[nt][h2][j] * mk[nt];
+          bv[nt] = __uint_as_float(__float_as_uint(bf[nt][h2][j]) & mk[nt]);
           if (p.square) bv[nt] *= bv[nt];
         }
 #pragma unroll

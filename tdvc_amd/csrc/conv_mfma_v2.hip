@@ -177,7 +177,8 @@ int launch_conv_v2(const ConvParams& p, int ntiles_unused, int cout_blocks, int 
   if (simple) q.slope = convk::conv_simple_slope(p);
   dim3 grid(q.tiles_x * tiles_y, cout_blocks, N);
   hipError_t err = hipSuccess;
-  static bool attr_done = false;
+  static TdvcPerDeviceFlag attr_flags;
+  bool& attr_done = attr_flags.flag();
   if (!attr_done) {
     err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (err == hipSuccess)

@@ -231,7 +231,8 @@ int launch_conv_v3(const ConvParams& p, int cout_blocks, int N, hipStream_t st) 
   if (gx < 1) gx = 1;
   if (gx > e.ntiles) gx = e.ntiles;
   dim3 grid(gx, cout_blocks, N);
-  static bool attr_done = false;
+  static TdvcPerDeviceFlag attr_flags;
+  bool& attr_done = attr_flags.flag();
   if (!attr_done) {
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (err == hipSuccess)

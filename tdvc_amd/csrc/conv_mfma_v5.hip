@@ -215,7 +215,8 @@ inline int v5_tl(int kh, int kw) { return ((WR + kh - 1) * (TW5 + kw - 1) * 4 + 
 
 template <int TL>
 int launch_tl(const ConvParams& q, const V5Extra& e, int mode, dim3 grid, int lds, hipStream_t st) {
-  static bool attr_done = false;
+  static TdvcPerDeviceFlag attr_flags;
+  bool& attr_done = attr_flags.flag();
   if (!attr_done) {
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v5_kernel<1, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err == hipSuccess)

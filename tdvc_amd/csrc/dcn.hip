@@ -541,7 +541,8 @@ extern "C" int tdvc_dcn_fused(const tdvc_dcn_desc* d, void* stream) {
                        p.x, p.x_sn, p.x_sp, p.npix, G, reinterpret_cast<half_t*>(d->x_planar));
   }
   if (g_dcn_lds && !p.xp && (long)d->x.H * d->x.W >= 8192) {
-    static bool attr_done = false;
+    static TdvcPerDeviceFlag attr_flags;
+  bool& attr_done = attr_flags.flag();
     if (!attr_done) {
       for (const void* k : {reinterpret_cast<const void*>(&dcn_lds_kernel<0>), reinterpret_cast<const void*>(&dcn_lds_kernel<1>),
                             reinterpret_cast<const void*>(&dcn_lds_kernel<2>)}) {

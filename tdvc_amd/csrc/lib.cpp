@@ -43,6 +43,7 @@ int tdvc_scratch_pages(const void** zeros, void** dump) {
     unsigned char* p = nullptr;
     err = hipMalloc(reinterpret_cast<void**>(&p), kZeroBytes + kDumpBytes);
     if (err == hipSuccess) err = hipMemset(p, 0, kZeroBytes + kDumpBytes);
+    if (err == hipSuccess) err = hipDeviceSynchronize();      // the fill runs on the null stream: complete before a launch on ANY stream reads the page
     if (err != hipSuccess) {
       if (p) (void)hipFree(p);
       tdvc_set_error("scratch pages: allocation on device %d failed: %s", dev, hipGetErrorString(err));

@@ -561,6 +561,8 @@ class Cheng2020Anchor(nn.Module, PackCache):
         cache = self.__dict__.setdefault("_ar_cache", {})
         key = (H, W, adt, str(dev), B)
         c = cache.get(key)
+        if c is not None and not all(a is b for a, b in zip(c["chain"]["pcs"], self._ar_packed())):
+            c = None                     # the packed weights were rebuilt since: the cached descriptors point at the old blobs
         if c is None:
             steps = self.wavefront_steps(H, W)
             flat = torch.tensor([p for st in steps for p in st], dtype=torch.int32, device=dev)
@@ -681,11 +683,18 @@ class Cheng2020Anchor(nn.Module, PackCache):
         t1 = FM.empty(1, 1, cap, ops.pad8(e[2].out_channels), dtype=adt, device=dev)
         gp = FM.empty(1, 1, cap, 2 * M, dtype=torch.float32, device=dev)
         v = lambda fm, c0, C_: FM(fm.t, c0, 1, C_)
-        descs = [ops.conv_desc(v(x1, 0, x1.C), self._ctx_1x1(), out=v(pc, 2 * M, 2 * M))[0],
-                 ops.conv_desc(v(pc, 0, 4 * M), pk_conv(self, "ep0", e[0]), out=t0, **LR)[0],
-                 ops.conv_desc(t0, pk_conv(self, "ep2", e[2]), out=t1, **LR)[0],
-                 ops.conv_desc(t1, pk_conv(self, "ep4", e[4]), out=gp, out_dtype=torch.float32)[0]]
-        return {"x1": x1, "pc": pc, "gp": gp, "descs": descs, "keep": (t0, t1)}
+        pcs = self._ar_packed()
+        descs = [ops.conv_desc(v(x1, 0, x1.C), pcs[0], out=v(pc, 2 * M, 2 * M))[0],
+                 ops.conv_desc(v(pc, 0, 4 * M), pcs[1], out=t0, **LR)[0],
+                 ops.conv_desc(t0, pcs[2], out=t1, **LR)[0],
+                 ops.conv_desc(t1, pcs[3], out=gp, out_dtype=torch.float32)[0]]
+        # the descriptors hold raw device pointers into the packed weights (and their fp32 twins): the chain keeps the packed objects
+        # alive, and _ar_setup() rebuilds it when the coder's packed forms are no longer these objects (clear_packed, refresh, .to())
+        return {"x1": x1, "pc": pc, "gp": gp, "descs": descs, "keep": (t0, t1), "pcs": pcs}
+
+    def _ar_packed(self):
+        e = self.entropy_parameters
+        return [self._ctx_1x1(), pk_conv(self, "ep0", e[0]), pk_conv(self, "ep2", e[2]), pk_conv(self, "ep4", e[4])]
 
     def _decode_wavefront(self, data, gct, table, y_hat, params):
         """one image of a wavefront-ordered y stream (tdvc_ar_wavefront, decoder direction)"""
