@@ -185,7 +185,8 @@ class TrainStep:
     def __init__(self, model, train_lambda: float = 2048.0, lr: float = 1e-4, loss_scale: float = 1024.0, clip: float = 2.0,
                  dynamic_scale: bool = True, growth_interval: int = 2000, graph: bool = False, graph_warmup: int = 2,
                  side_stream: bool = True, scale_update: str = "exact", freeze_gc: bool = True):
-        """freeze_gc: after the third step (model, packed weights, descriptor caches and pools exist by then) everything alive
+        """freeze_gc: after the second step (model, packed weights, descriptor caches and pools exist by then; bench.py's three warm-up steps
+        include the collection) everything alive
         moves to the garbage collector's permanent generation (gc.freeze): a step allocates ~50 k short-lived containers (tape
         closures, descriptors), which triggers full collections, and each of those walked the whole heap of the process --
         40-75 ms once or twice per 30 steps (+2.3 ms per step on average, tools/train_back_to_back.py).
@@ -272,7 +273,7 @@ class TrainStep:
     def __call__(self, input_image: torch.Tensor, refer_frames: torch.Tensor) -> dict:
         model = self.model
         self._calls += 1
-        if self._calls == 4 and self.freeze_gc:
+        if self._calls == 3 and self.freeze_gc:
             gc.collect()
             gc.freeze()
         self._settle(block=self.dynamic_scale and self.scale_update == "exact")

@@ -303,3 +303,53 @@ def test_tape_deferred_chains_run_behind_the_sweep():
     assert log == ["node_b", "done0", "node_a", "done1", "join", "chain", "join"], log
     assert tape.touch_log[id(p1)] == 1 and tape.touch_log[id(p2)] == 2 == tape.n_backward_nodes
     assert not tape.deferred and not tape.nodes
+
+
+def test_step_log_is_lazy_and_settles_the_loss_scale_in_order():
+    """train.StepLog / TrainStep._settle (host logic only, CPU tensors): GradScaler.update()'s bookkeeping -- halve on a non-finite
+    gradient norm, double after `growth_interval` clean steps -- is applied to the pending steps oldest first, exactly once, whether the
+    log is read or the next step settles it; a skipped step reports grad_norm NaN and the scale AFTER its update"""
+    from tdvc_amd.train import StepLog, TrainStep
+    ts = TrainStep.__new__(TrainStep)
+    ts.dynamic_scale, ts.growth_interval, ts._clean_steps, ts.loss_scale, ts._pending = True, 2, 0, 64.0, []
+
+    def step(found):
+        log = StepLog(ts, torch.tensor([9.5, 0.1, 1.0, 2.0, 30.0, 4.0, float(found)]))
+        ts._pending.append(log)
+        return log
+
+    a, b, c = step(0), step(1), step(0)
+    assert ts.loss_scale == 64.0 and len(ts._pending) == 3             # nothing settled yet: nobody read a log
+    assert c["loss_scale"] == 32.0 and not c["skipped"]                 # reading the LAST log settles all three, in order
+    assert ts._pending == [] and ts.loss_scale == 32.0 and ts._clean_steps == 1
+    assert b["skipped"] and b["loss_scale"] == 32.0 and b["grad_norm"] != b["grad_norm"]
+    assert a["loss_scale"] == 64.0 and a["rd_loss"] == 9.5 and abs(a["grad_norm"] - 4.0) < 1e-6 and set(a) == set(StepLog.KEYS)
+    d = step(0)
+    ts._settle()                                                        # what the next step's start does
+    assert ts.loss_scale == 64.0 and d["loss_scale"] == 64.0            # second clean step in a row: growth_interval = 2
+    ts.dynamic_scale = False
+    e = step(1)
+    assert e["skipped"] and ts.loss_scale == 64.0                       # a static scale never moves; the step is still reported as skipped
+
+
+def test_mirror_pool_carves_zeroed_aligned_mirrors_from_arenas():
+    """autograd.MirrorPool.get: mirrors are views of a few large zeroed arenas (256-byte aligned, the original's shape and dtype), a
+    non-contiguous original gets its own buffer, and a recycled mirror is handed out again for the same key"""
+    from tdvc_amd.autograd import MirrorPool
+    pool = MirrorPool()
+    pool.ARENA_BYTES = 1 << 16
+    x16, x32 = torch.empty(2, 5, 7, 8, dtype=torch.float16), torch.empty(3, 9, dtype=torch.float32)
+    m16, m32 = pool.get(x16), pool.get(x32)
+    assert m16.shape == x16.shape and m16.dtype == torch.float16 and m32.shape == x32.shape and m32.dtype == torch.float32
+    assert float(m16.abs().sum()) == 0.0 and float(m32.abs().sum()) == 0.0
+    base = pool.arenas[0][0]
+    # offsets inside an arena are multiples of 256 bytes (the arena itself is as aligned as the device allocator makes it: 512 B on the GPU)
+    assert (m16.data_ptr() - base.data_ptr()) % 256 == 0 and (m32.data_ptr() - base.data_ptr()) % 256 == 0 and len(pool.arenas) == 1
+    assert base.data_ptr() <= m32.data_ptr() < base.data_ptr() + base.numel()
+    big = pool.get(torch.empty(40000, dtype=torch.float16))             # does not fit the rest of the first arena: a second one
+    assert len(pool.arenas) == 2 and big.numel() == 40000
+    nc = torch.empty(4, 6, dtype=torch.float16).t()
+    loose = pool.get(nc)
+    assert loose.shape == nc.shape and len(pool.loose) == 1
+    pool.free.setdefault((tuple(x16.shape), x16.dtype, x16.device), []).append(m16)      # what recycle() does after the fills
+    assert pool.get(x16) is m16
