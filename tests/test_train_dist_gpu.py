@@ -150,3 +150,22 @@ def test_bench_train_mode_under_one_rank_rccl_group(report):
     report(f"bench.py --mode train under a 1-rank nccl group: {line['ms_per_step']} ms/step at batch 2; ranks_seen {seen}")
     assert line["n_gpus"] == 1 and line["value"] > 0 and len(seen) == 1
     assert seen[0]["rank"] == 0 and seen[0]["rccl"] and (seen[0]["uuid"] or seen[0]["pci"])
+
+
+def test_bench_inference_mode_under_one_rank_rccl_group(report):
+    """the default (inference, GOP-sharded) mode of `bench.py` under a ONE-rank RCCL process group: what the driver's N > 1 scaling runs
+    execute -- nccl init with the rank's device, GOP seeds per rank, barrier / max-over-ranks timing, `ranks_seen` -- minus the legs that
+    only rank 0 of a one-GPU run adds (`--no-extras --no-pmc --no-cpu-baseline`)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               TDVC_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-extras", "--no-pmc",
+                        "--no-cpu-baseline"], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    report(f"bench.py (inference) under a 1-rank nccl group: {line['value']} frames/s, {line['ms_per_step']} ms/frame; ranks_seen {line['ranks_seen']}")
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["value"] > 0 and line["scaling"] == "weak"
+    assert len(line["ranks_seen"]) == 1 and line["ranks_seen"][0]["rccl"]
