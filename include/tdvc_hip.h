@@ -462,6 +462,16 @@ int tdvc_mul2_accumulate(const tdvc_fmap* dx, const tdvc_fmap* x, const tdvc_fma
  * tdvc_gc_backward: dy += gscale * dbits/dy, dgp[.., 0:M] (scales) and dgp[.., M:2M] (means) likewise. */
 int tdvc_eb_backward(const tdvc_fmap* z, const float* params, const tdvc_fmap* noise, float gscale, const tdvc_fmap* dz, float* dparams, void* stream);
 int tdvc_gc_backward(const tdvc_fmap* y, const tdvc_fmap* gp, const tdvc_fmap* noise, float gscale, const tdvc_fmap* dy, const tdvc_fmap* dgp, void* stream);
+/* The factorised prior's parameter-space work of a training step (compressai EntropyBottleneck: `_logits_cumulative`'s softplus / tanh
+ * reparametrisation and `loss()`, the auxiliary quantile loss; the reference's tools/train.py:150-151 runs the latter through autograd).
+ * `raw` / `grad`: DEVICE arrays of 14 pointers -- _matrix0..4, _bias0..4, _factor0..3, each [C][len] fp32 -- in the column order of the
+ * packed table [C][59] that tdvc_eb_forward / tdvc_eb_backward read.
+ * tdvc_eb_pack: packed = softplus(matrices) | biases | tanh(factors) | median (quantiles[c][1]).
+ * tdvc_eb_param_chain: grad[k] += scale * dpacked * d packed / d raw (the median column is skipped).
+ * tdvc_eb_aux: loss[0] = sum |logits_cumulative(quantiles) - (-target, 0, +target)|, dq[C][3] = its gradient (overwritten); 3 C <= 1024. */
+int tdvc_eb_pack(const float* const* raw, const float* quantiles, float* packed, int C, void* stream);
+int tdvc_eb_param_chain(const float* dpacked, const float* const* raw, float* const* grad, float scale, int C, void* stream);
+int tdvc_eb_aux(const float* params, const float* quantiles, float target, float* dq, float* loss, int C, void* stream);
 
 /* fp16 channel-innermost pieces of the fused DCN's backward (dcn_v2_cuda.cu:97-216 restructured): column channel
  * k = group*72 + tap*8 + j.  tdvc_dcn_columns: col = mask * bilinear samples (operand of dW = dY col^T, a 1x1

@@ -240,7 +240,11 @@ class EntropyBottleneck(_CdfBuffers, nn.Module):
                 self.register_parameter(f"_factor{i:d}", nn.Parameter(torch.zeros(channels, f[i + 1], 1)))
         q = torch.Tensor([-self.init_scale, 0, self.init_scale])
         self.quantiles = nn.Parameter(q.repeat(channels, 1, 1))
-        self.register_buffer("target", torch.Tensor([np.log(2 / self.tail_mass - 1)]))
+        target = np.log(2 / self.tail_mass - 1)
+        # compressai EntropyBottleneck.__init__: the three quantiles are driven to the logits (-t, 0, +t), i.e. to the tail_mass / 2,
+        # 1 / 2 and 1 - tail_mass / 2 quantiles.  (Rounds 1-3 registered the single value [t]: with it all three quantiles chase the
+        # upper tail and the median column drifts -- found in round 4 when the auxiliary loss became a kernel.)
+        self.register_buffer("target", torch.Tensor([-target, 0, target]))
 
     def medians(self):
         return self.quantiles[:, :, 1:2]

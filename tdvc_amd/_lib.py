@@ -91,6 +91,9 @@ SIGNATURES = {
     "tdvc_axpy_f32": (_i, [_P, _P, _f, _i64, _P]),
     "tdvc_match_gather_backward": (_i, [_FM, _FM, _P, _i, _i, _i, _FM, _FM, _FM, _P]),
     "tdvc_eb_backward": (_i, [_FM, _P, _FM, _f, _FM, _P, _P]),
+    "tdvc_eb_pack": (_i, [_P, _P, _P, _i, _P]),
+    "tdvc_eb_param_chain": (_i, [_P, _P, _P, _f, _i, _P]),
+    "tdvc_eb_aux": (_i, [_P, _P, _f, _P, _P, _i, _P]),
     "tdvc_gc_backward": (_i, [_FM, _FM, _FM, _f, _FM, _FM, _P]),
     "tdvc_dcn_columns": (_i, [_FM, _FM, _i, _FM, _P]),
     "tdvc_ar_decode_serial": (_i, [_P, _i64, _P, _i, _P, _P, _FM, _FM, _FM, _FM, _P, _i, _FM, _P, _i, _i, _i, _P, _i, _P, _P, _P]),

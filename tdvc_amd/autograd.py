@@ -413,7 +413,7 @@ def record_eb_forward(tape: Tape, z: FM, params: torch.Tensor, z_hat: FM, noise)
         ops.eb_backward(z, params, noise, tape.rate_grad * tape.loss_scale, dz, dp)
 
         def chain():                              # softplus / tanh chain to the raw parameters as torch kernels: behind the sweep (Tape.defer)
-            owner.accumulate_param_grads(dp * tape.inv_scale)
+            owner.accumulate_param_grads(dp, tape.inv_scale)
             tape.touch(*owner.parameters())
         tape.defer(chain)
 

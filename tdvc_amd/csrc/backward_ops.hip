@@ -964,6 +964,92 @@ extern "C" int tdvc_mul2_accumulate(const tdvc_fmap* dx, const tdvc_fmap* x, con
   return tdvc_launch_status("tdvc_mul2_accumulate");
 }
 
+// ---- the factorised prior's PARAMETER-SPACE work of a training step as three launches (it was ~170 torch launches per coder: softplus / tanh
+// / matmul / add chains with their autograd twins, 128 x 59 values each).  Column layout of the packed table = eb_logits()'s: softplus(matrix0..4)
+// [33] | bias0..4 [13] | tanh(factor0..3) [12] | median.  `raw` / `grad`: device tables of the 14 parameter tensors in that order (each [C][len]).
+struct EbCol { int k, j, len; };
+__device__ __forceinline__ EbCol eb_col(int col) {      // packed column -> (parameter index, element inside the channel's block, block length)
+  constexpr int start[15] = {0, 3, 12, 21, 30, 33, 36, 39, 42, 45, 46, 49, 52, 55, 58};
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < 14; ++i) k += col >= start[i] ? 1 : 0;
+  return EbCol{k, col - start[k], start[k + 1] - start[k]};
+}
+__device__ __forceinline__ float softplus_t(float x) { return x > 20.f ? x : log1pf(expf(x)); }      // torch.nn.functional.softplus (beta 1, threshold 20)
+
+__global__ void eb_pack_kernel(const float* const* raw, const float* quantiles, float* packed, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * EBP) return;
+  const int c = i / EBP, col = i - c * EBP;
+  if (col == 58) { packed[i] = quantiles[c * 3 + 1]; return; }
+  const EbCol e = eb_col(col);
+  const float x = raw[e.k][c * e.len + e.j];
+  packed[i] = col < 33 ? softplus_t(x) : (col < 46 ? x : tanhf(x));
+}
+
+// grad[k][c][j] += scale * dpacked[c][col] * d packed / d raw (softplus' = sigmoid, with torch's threshold; tanh' = 1 - tanh^2); the median column
+// (the quantiles) only receives the auxiliary loss
+__global__ void eb_param_chain_kernel(const float* dpacked, const float* const* raw, float* const* grad, float scale, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * EBP) return;
+  const int c = i / EBP, col = i - c * EBP;
+  if (col == 58) return;
+  const EbCol e = eb_col(col);
+  const float x = raw[e.k][c * e.len + e.j];
+  float d = 1.f;
+  if (col < 33) d = x > 20.f ? 1.f : sigm(x);
+  else if (col >= 46) { const float t = tanhf(x); d = 1.f - t * t; }
+  grad[e.k][c * e.len + e.j] += scale * dpacked[i] * d;
+}
+
+// compressai's auxiliary loss: sum_c sum_j |logits_cumulative(quantiles[c][j]) - target_j| (targets -t, 0, +t), parameters held constant;
+// dq[c][j] = its gradient (overwritten), loss[0] = its value.  One workgroup (3 C <= 1024 threads), fixed summation order.
+__global__ __launch_bounds__(1024) void eb_aux_kernel(const float* params, const float* quantiles, float target, float* dq, float* loss, int C) {
+  __shared__ float sh[16];
+  const int i = threadIdx.x;
+  float l = 0.f;
+  if (i < 3 * C) {
+    const int c = i / 3, j = i - 3 * c;
+    const float* P = params + (long)c * EBP;
+    const float v = quantiles[i];
+    const float tj = j == 0 ? -target : (j == 2 ? target : 0.f);
+    const float r = eb_logits(P, v) - tj;
+    const float sg = r > 0.f ? 1.f : (r < 0.f ? -1.f : 0.f);
+    float gp[EBP];
+#pragma unroll
+    for (int q = 0; q < EBP; ++q) gp[q] = 0.f;
+    dq[i] = eb_logits_backward(P, v, sg, gp);
+    l = fabsf(r);
+  }
+  for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+  if ((i & 63) == 0) sh[i >> 6] = l;
+  __syncthreads();
+  if (i == 0) {
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+    loss[0] = t;
+  }
+}
+
+extern "C" int tdvc_eb_pack(const float* const* raw, const float* quantiles, float* packed, int C, void* stream) {
+  TDVC_CHECK(raw && quantiles && packed && C >= 1, "tdvc_eb_pack: bad arguments");
+  hipLaunchKernelGGL(eb_pack_kernel, grid1d((long)C * EBP, 256), dim3(256), 0, ST(stream), raw, quantiles, packed, C);
+  return tdvc_launch_status("tdvc_eb_pack");
+}
+
+extern "C" int tdvc_eb_param_chain(const float* dpacked, const float* const* raw, float* const* grad, float scale, int C, void* stream) {
+  TDVC_CHECK(dpacked && raw && grad && C >= 1, "tdvc_eb_param_chain: bad arguments");
+  hipLaunchKernelGGL(eb_param_chain_kernel, grid1d((long)C * EBP, 256), dim3(256), 0, ST(stream), dpacked, raw, grad, scale, C);
+  return tdvc_launch_status("tdvc_eb_param_chain");
+}
+
+extern "C" int tdvc_eb_aux(const float* params, const float* quantiles, float target, float* dq, float* loss, int C, void* stream) {
+  TDVC_CHECK(params && quantiles && dq && loss && C >= 1 && 3 * C <= 1024, "tdvc_eb_aux: bad arguments (3 C <= 1024)");
+  const int threads = ((3 * C + 63) / 64) * 64;
+  hipLaunchKernelGGL(eb_aux_kernel, dim3(1), dim3(threads), 0, ST(stream), params, quantiles, target, dq, loss, C);
+  return tdvc_launch_status("tdvc_eb_aux");
+}
+
 extern "C" int tdvc_eb_backward(const tdvc_fmap* z, const float* params, const tdvc_fmap* noise, float gscale, const tdvc_fmap* dz, float* dparams, void* stream) {
   TDVC_CHECK(z && params && noise && dz && dparams && fmap_ok32(*z) && fmap_ok32(*noise) && fmap_ok32(*dz) && same_geom(*z, *noise) && same_geom(*z, *dz) &&
                  noise->C >= z->C && dz->C >= z->C, "tdvc_eb_backward: bad arguments");

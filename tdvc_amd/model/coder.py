@@ -268,7 +268,11 @@ class EntropyBottleneck(_CdfBuffers, nn.Module, PackCache):
                 self.register_parameter(f"_factor{i:d}", nn.Parameter(torch.zeros(channels, f[i + 1], 1)))
         q = torch.Tensor([-self.init_scale, 0, self.init_scale])
         self.quantiles = nn.Parameter(q.repeat(channels, 1, 1))
-        self.register_buffer("target", torch.Tensor([np.log(2 / self.tail_mass - 1)]))
+        target = np.log(2 / self.tail_mass - 1)
+        # compressai EntropyBottleneck.__init__: the three quantiles are driven to the logits (-t, 0, +t), i.e. to the tail_mass / 2,
+        # 1 / 2 and 1 - tail_mass / 2 quantiles.  (Rounds 1-3 registered the single value [t]: with it all three quantiles chase the
+        # upper tail and the median column drifts -- found in round 4 when the auxiliary loss became a kernel.)
+        self.register_buffer("target", torch.Tensor([-target, 0, target]))
 
     def _packed_tensor(self) -> torch.Tensor:
         """[C][59] fp32: softplus(matrix0..4) | bias0..4 | tanh(factor0..3) | median"""
@@ -289,17 +293,57 @@ class EntropyBottleneck(_CdfBuffers, nn.Module, PackCache):
             return p
         return self._pk("eb", build)
 
-    def refresh_packed(self):
-        self.__dict__.get("_packed", {}).pop("eb", None)
+    def _raw_params(self):
+        """the 14 parameter tensors behind the packed table, in its column order"""
+        return ([getattr(self, f"_matrix{i}") for i in range(5)] + [getattr(self, f"_bias{i}") for i in range(5)] +
+                [getattr(self, f"_factor{i}") for i in range(4)])
 
-    def accumulate_param_grads(self, dpacked: torch.Tensor):
-        """chain rule through softplus / tanh (parameter space, 128 x 59 values: plain autograd); the median column
-        (quantiles) only receives the auxiliary loss"""
+    def _ptr_table(self, name, tensors):
+        """device array of the tensors' addresses (tdvc_eb_pack / tdvc_eb_param_chain), rebuilt when one of them moved"""
+        ptrs = tuple(t.data_ptr() for t in tensors)
+        c = self.__dict__.get(name)
+        if c is None or c[0] != ptrs:
+            assert all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in tensors)
+            c = self.__dict__[name] = (ptrs, torch.tensor(ptrs, dtype=torch.int64, device=tensors[0].device))
+        return c[1]
+
+    def refresh_packed(self):
+        """after an optimizer step: the packed table follows the parameters -- in place, one launch (tdvc_eb_pack), when it exists"""
+        p = self.__dict__.get("_packed", {}).get("eb")
+        if p is None:
+            return
+        if not p.is_cuda:
+            self.__dict__["_packed"].pop("eb", None)
+            return
+        raw = self._raw_params()
+        ops.eb_pack(self._ptr_table("_raw_table", [t.data for t in raw]), self.quantiles.data, p, self.channels)
+
+    def accumulate_param_grads(self, dpacked: torch.Tensor, scale: float = 1.0):
+        """chain rule through softplus / tanh into the 14 raw parameters (128 x 58 values); the median column (quantiles) only receives
+        the auxiliary loss.  On the device: one launch (tdvc_eb_param_chain) instead of autograd over ~40 element-wise kernels."""
+        if dpacked.is_cuda:
+            from ..autograd import param_grad
+            raw = self._raw_params()
+            grads = [param_grad(t) for t in raw]
+            ops.eb_param_chain(dpacked, self._ptr_table("_raw_table", [t.data for t in raw]), self._ptr_table("_grad_table", grads), scale, self.channels)
+            return
         with torch.enable_grad():
             p = self._packed_tensor()
-            d = dpacked.clone()
+            d = dpacked * scale
             d[:, 58] = 0.0
             torch.autograd.backward([p], [d])
+
+    @torch.no_grad()
+    def loss_fused(self) -> torch.Tensor:
+        """`loss()` and its gradient in one launch (tdvc_eb_aux): -> the loss as a 1-element fp32 tensor; `quantiles.grad` is OVERWRITTEN
+        with d loss / d quantiles.  The matrices / biases / factors are those of the packed table, i.e. of the last forward -- what the
+        reference's `aux_loss.backward()` differentiates too (its graph was built in the forward, tools/train.py:150)."""
+        q = self.quantiles
+        if q.grad is None or q.grad.shape != q.shape:
+            q.grad = torch.empty_like(q)
+        out = torch.empty(1, dtype=torch.float32, device=q.device)
+        ops.eb_aux(self.packed_params(), q.data, float(np.log(2 / self.tail_mass - 1)), q.grad, out, self.channels)
+        return out
 
     def logits_cumulative(self, x, stop_gradient):
         for i in range(len(self.filters) + 1):

@@ -1021,6 +1021,20 @@ def eb_forward(z: FM, params: torch.Tensor, z_hat: FM, bits_out: torch.Tensor, n
     _rec("eb_forward", z, params, z_hat, noise)
 
 
+def eb_pack(raw_table: torch.Tensor, quantiles: torch.Tensor, packed: torch.Tensor, Cn: int) -> None:
+    L.check(L.lib().tdvc_eb_pack(raw_table.data_ptr(), quantiles.data_ptr(), packed.data_ptr(), Cn, _stream()), "eb_pack")
+
+
+def eb_param_chain(dpacked: torch.Tensor, raw_table: torch.Tensor, grad_table: torch.Tensor, scale: float, Cn: int) -> None:
+    assert dpacked.is_contiguous() and dpacked.dtype == torch.float32 and tuple(dpacked.shape) == (Cn, 59)
+    L.check(L.lib().tdvc_eb_param_chain(dpacked.data_ptr(), raw_table.data_ptr(), grad_table.data_ptr(), scale, Cn, _stream()), "eb_param_chain")
+
+
+def eb_aux(params: torch.Tensor, quantiles: torch.Tensor, target: float, dq: torch.Tensor, loss: torch.Tensor, Cn: int) -> None:
+    assert quantiles.is_contiguous() and dq.is_contiguous() and quantiles.numel() == 3 * Cn == dq.numel() and dq.dtype == torch.float32
+    L.check(L.lib().tdvc_eb_aux(params.data_ptr(), quantiles.data_ptr(), target, dq.data_ptr(), loss.data_ptr(), Cn, _stream()), "eb_aux")
+
+
 def eb_backward(z: FM, params: torch.Tensor, noise: FM, gscale: float, dz: FM, dparams: torch.Tensor) -> None:
     d1, d2, d3 = z.desc(), noise.desc(), dz.desc()
     L.check(L.lib().tdvc_eb_backward(C.byref(d1), params.data_ptr(), C.byref(d2), gscale, C.byref(d3), dparams.data_ptr(), _stream()), "eb_backward")

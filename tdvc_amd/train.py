@@ -279,8 +279,9 @@ class TrainStep:
         self._settle(block=self.dynamic_scale and self.scale_update == "exact")
         if not (model.training and model.mvCoder.training and model.resCoder.training):
             model.train()                              # a recursive walk over ~480 modules: only when the mode actually changes
-        for p in self.aux_params:
-            p.grad = None
+        if not self._fused:
+            for p in self.aux_params:
+                p.grad = None                          # (the fused auxiliary loss overwrites its gradients)
         if self.use_graph and self._eager_steps >= self.graph_warmup:
             if (self._graph is None or self._graph_scale != self.loss_scale or self._static_in[0].shape != input_image.shape
                     or self._static_in[1].shape != refer_frames.shape):
@@ -311,8 +312,14 @@ class TrainStep:
                 for b in self.buckets.buckets:
                     b.mul_(coef)
                 self.optimizer.step()
-        aux = model.mvCoder.aux_loss() + model.resCoder.aux_loss()      # pnet.py's forward returns exactly these two
-        aux.backward()
+        if self._fused:
+            # the auxiliary quantile loss of both coders and its gradient: one launch each, on the forward's parameter values (the packed
+            # tables are re-packed below) -- what `aux_loss.backward()` differentiates in tools/train.py:150, whose graph dates from the forward
+            a1, a2 = model.mvCoder.entropy_bottleneck.loss_fused(), model.resCoder.entropy_bottleneck.loss_fused()
+            aux = (a1 + a2).reshape(())
+        else:
+            aux = model.mvCoder.aux_loss() + model.resCoder.aux_loss()      # pnet.py's forward returns exactly these two
+            aux.backward()
         self.aux_optimizer.step()
         refresh_packed(model)
         vals = torch.stack([self.lam * mse + bpp_res + bpp_mv, mse, bpp_res, bpp_mv, aux.detach().float(), gnorm, found])

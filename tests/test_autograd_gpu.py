@@ -666,3 +666,50 @@ def test_full_model_backward_cfg3_shape(report):
     # whole gradient <= 2e-2; per tensor: 90 % under 6e-2, none above 0.2 (fp16 activations / activation gradients: sign
     # flips of ReLU / LeakyReLU pre-activations near zero dominate the small tensors)
     assert tot < 2e-2 and errs[int(0.9 * len(errs))][0] < 6e-2 and errs[-1][0] < 0.2
+
+
+@pytest.mark.parametrize("C", [128, 64])
+def test_entropy_bottleneck_parameter_space_kernels(C, report):
+    """the factorised prior's parameter-space work as three launches (tdvc_eb_pack / tdvc_eb_param_chain / tdvc_eb_aux) against the torch
+    expressions they replace (compressai EntropyBottleneck: softplus / tanh reparametrisation, `loss()` with targets (-t, 0, +t))"""
+    from tdvc_amd.model.coder import EntropyBottleneck
+    torch.manual_seed(7)
+    eb = EntropyBottleneck(C).cuda()
+    with torch.no_grad():
+        for n, p in eb.named_parameters():
+            p.add_(torch.randn_like(p) * (0.3 if "matrix" in n else 0.2))
+        eb._matrix1[0, 0, 0] = 25.0                      # beyond softplus's threshold (20): the identity branch
+    want = eb._packed_tensor().detach()
+    got = eb.packed_params()                             # built by the torch expression ...
+    eb.refresh_packed()                                  # ... and re-packed in place by the kernel
+    assert got.data_ptr() == eb.packed_params().data_ptr()
+    e_pack = float((got - want).abs().max())
+    assert e_pack <= 2e-6, e_pack
+    # parameter chain: autograd through the torch expression against the kernel
+    d = torch.randn(C, 59, device="cuda")
+    for p in eb.parameters():
+        p.grad = None
+    with torch.enable_grad():
+        pt = eb._packed_tensor()
+        dd = d.clone()
+        dd[:, 58] = 0.0
+        torch.autograd.backward([pt], [dd * 0.5])
+    ref = {n: p.grad.clone() for n, p in eb.named_parameters() if p.grad is not None}
+    for p in eb.parameters():
+        p.grad = None
+    eb.accumulate_param_grads(d, 0.5)
+    eb.accumulate_param_grads(d, 0.5)                    # accumulates: twice the reference
+    e_chain = max(float((p.grad - 2 * ref[n]).abs().max() / (ref[n].abs().max() + 1e-12)) for n, p in eb.named_parameters() if n in ref and n != "quantiles")
+    assert float(ref["quantiles"].abs().max()) == 0.0 and len(ref) == 15      # autograd: a zero gradient for the median column; 14 raw tensors
+    assert eb.quantiles.grad is None or float(eb.quantiles.grad.abs().max()) == 0.0
+    assert e_chain <= 1e-5, e_chain
+    # auxiliary loss and its gradient
+    with torch.enable_grad():
+        loss = eb.loss()
+        (gq,) = torch.autograd.grad(loss, [eb.quantiles])
+    lf = eb.loss_fused()
+    e_loss = abs(float(lf) - float(loss)) / abs(float(loss))
+    e_dq = float((eb.quantiles.grad - gq).abs().max() / gq.abs().max())
+    report(f"entropy bottleneck C={C}: pack max |d| {e_pack:.1e}, parameter chain rel {e_chain:.1e}, aux loss {float(loss):.4f} rel {e_loss:.1e}, d quantiles rel {e_dq:.1e}")
+    assert e_loss <= 1e-5 and e_dq <= 1e-4
+    assert tuple(eb.target.shape) == (3,) and float(eb.target[0]) == -float(eb.target[2]) and float(eb.target[1]) == 0.0
