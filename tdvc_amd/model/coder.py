@@ -334,15 +334,23 @@ class EntropyBottleneck(_CdfBuffers, nn.Module, PackCache):
             torch.autograd.backward([p], [d])
 
     @torch.no_grad()
-    def loss_fused(self) -> torch.Tensor:
-        """`loss()` and its gradient in one launch (tdvc_eb_aux): -> the loss as a 1-element fp32 tensor; `quantiles.grad` is OVERWRITTEN
-        with d loss / d quantiles.  The matrices / biases / factors are those of the packed table, i.e. of the last forward -- what the
-        reference's `aux_loss.backward()` differentiates too (its graph was built in the forward, tools/train.py:150)."""
+    def loss_fused(self, write_grad: bool = True) -> torch.Tensor:
+        """`loss()` and its gradient in one launch (tdvc_eb_aux): -> the loss as a 1-element fp32 tensor; with `write_grad`
+        `quantiles.grad` is OVERWRITTEN with d loss / d quantiles (otherwise the gradient goes to a scratch buffer: the training-mode
+        forward under the tape only reports the value).  The matrices / biases / factors are those of the packed table, i.e. of the
+        last forward -- what the reference's `aux_loss.backward()` differentiates too (its graph was built in the forward,
+        tools/train.py:150)."""
         q = self.quantiles
-        if q.grad is None or q.grad.shape != q.shape:
-            q.grad = torch.empty_like(q)
+        if write_grad:
+            if q.grad is None or q.grad.shape != q.shape:
+                q.grad = torch.empty_like(q)
+            dq = q.grad
+        else:
+            dq = self.__dict__.get("_dq_scratch")
+            if dq is None or dq.device != q.device:
+                dq = self.__dict__["_dq_scratch"] = torch.empty_like(q)
         out = torch.empty(1, dtype=torch.float32, device=q.device)
-        ops.eb_aux(self.packed_params(), q.data, float(np.log(2 / self.tail_mass - 1)), q.grad, out, self.channels)
+        ops.eb_aux(self.packed_params(), q.data, float(np.log(2 / self.tail_mass - 1)), dq, out, self.channels)
         return out
 
     def logits_cumulative(self, x, stop_gradient):
@@ -509,7 +517,13 @@ class Cheng2020Anchor(nn.Module, PackCache):
         return x_hat, bits
 
     def aux_loss(self):
-        return self.entropy_bottleneck.loss()
+        """compressai `aux_loss()`.  Under this build's tape (training through tdvc_amd.autograd, where nothing carries a torch graph) the
+        value comes from one kernel; `TrainStep` obtains its gradient the same way (EntropyBottleneck.loss_fused).  Outside the tape: the
+        torch expression with its autograd graph, as in compressai."""
+        eb = self.entropy_bottleneck
+        if ops.TAPE is not None and eb.quantiles.is_cuda:
+            return eb.loss_fused(write_grad=False).reshape(())
+        return eb.loss()
 
     # -- entropy coding (`main/model/pnet.py:45-49,69-73`) -----------------------------------
     @torch.no_grad()
