@@ -121,6 +121,13 @@ class Tape:
     def grad_tensor(self, t: torch.Tensor) -> torch.Tensor:
         return self._base(t)
 
+    def zeros_like(self, t: torch.Tensor) -> torch.Tensor:
+        """a zeroed scratch accumulator for this sweep (parameter-space gradients that go through a chain before they reach `.grad`): from the
+        mirror pool when there is one (re-zeroed with the arenas, no fill launch of its own), else a fresh tensor"""
+        if self.pool is not None and t.is_contiguous() and t.dtype in (torch.float32, torch.float16):
+            return self.pool.get(t.detach())
+        return torch.zeros_like(t)
+
     def needs_grad(self, fm: FM) -> bool:
         return fm.t.data_ptr() not in self.nograd
 
@@ -385,8 +392,7 @@ def record_gdn(tape: Tape, x: FM, pc, y: FM, res, gdn):
         dn = ops.gdn_backward(g, x, n32, gdn == ops.GDN_INV, dx)
         t = ops.conv_dgrad(pc, dn, FM.empty(x.N, x.H, x.W, x.C, device=x.t.device), accumulate=False)
         ops.mul2_accumulate(dx, x, t)
-        dgamma = torch.zeros_like(pc.wsrc)
-        dbeta = torch.zeros_like(pc.bsrc)
+        dgamma, dbeta = tape.zeros_like(pc.wsrc), tape.zeros_like(pc.bsrc)
         ops.conv_wgrad(pc, dn, x, dgamma.view(-1), scale=tape.inv_scale, square_x=True, db=dbeta)
 
         # the chain through the reparametrisation runs behind the sweep (Tape.defer), for all GDN layers of the step at once
@@ -409,7 +415,7 @@ def record_eb_forward(tape: Tape, z: FM, params: torch.Tensor, z_hat: FM, noise)
     def bwd():
         dz = tape.grad(z)
         accumulate(dz, tape.grad(z_hat))          # z_hat = z + noise
-        dp = torch.zeros_like(params)
+        dp = tape.zeros_like(params)
         ops.eb_backward(z, params, noise, tape.rate_grad * tape.loss_scale, dz, dp)
 
         def chain():                              # softplus / tanh chain to the raw parameters as torch kernels: behind the sweep (Tape.defer)
