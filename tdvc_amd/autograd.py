@@ -21,6 +21,7 @@ from . import ops
 from .ops import FM
 
 
+LAZY_IDENTITY = True           # A/B switch: identity gradients of residual connections as the next dgrad conv's residual operand (Tape.add_identity)
 BATCH_WGRAD_REDUCE = True        # A/B switch (tools/ab_train.py): False = one reduce launch per layer, right behind its first stage
 
 
@@ -100,12 +101,14 @@ class Tape:
         # executed after the sweep AND after join(), when no MFMA kernel runs on the side stream any more -- torch's own device code is
         # built WITH packed-FP32 instructions, and its softplus kernels contain the `v_pk_*_f32 ... op_sel:[0,1]` form that returned
         # wrong values next to a concurrent MFMA stream (profiles/r04_torch_packed_fp32_scan.txt)
+        self.touched: set = set()                 # activation buffers whose gradient mirror has been handed out
+        self.pending: dict = {}                   # buffer -> (view, identity gradient) not yet added to its mirror (add_identity)
         self.deferred: list = []
         self.gdn_items: list = []                 # (GDN module, d gamma_eff, d beta_eff) of this sweep: one batched chain (coder.gdn_chain_batched)
         self._ev, self._side_raw = None, None
 
     # ------------------------------------------------------------------ gradient views
-    def _base(self, t: torch.Tensor) -> torch.Tensor:
+    def _mirror(self, t: torch.Tensor) -> torch.Tensor:
         key = t.data_ptr()
         g = self.gbuf.get(key)
         if g is None:
@@ -113,6 +116,43 @@ class Tape:
             self.gbuf[key] = g
             self.keep.append(t)
         return g
+
+    def _base(self, t: torch.Tensor) -> torch.Tensor:
+        """the mirror of `t`, handed out: from now on it may hold a partial sum, and an identity gradient still waiting for it is added first"""
+        key = t.data_ptr()
+        g = self._mirror(t)
+        self.touched.add(key)
+        p = self.pending.pop(key, None)
+        if p is not None:
+            pf, src = p
+            accumulate(FM(g, pf.off, pf.N, pf.C, pf.sn), src)
+        return g
+
+    # Identity gradients of residual connections (y = conv(...) + x: grad(x) += grad(y)) were one add kernel each, 63 launches per step, in front
+    # of the dgrad conv that then accumulates into the same mirror (reading it as its residual operand).  Deferred instead: when the next
+    # writer of that mirror is a dgrad conv and nothing else has touched the mirror, the identity gradient IS the conv's residual operand and
+    # the mirror is overwritten -- the same fp16 sum of the same two values, bit for bit, without the add and without reading zeros.
+    def add_identity(self, fm: FM, src: FM):
+        """grad(fm) += src, possibly later (src is final: a mirror whose producers have all run, or a temporary the tape keeps).
+        -> True when the add was deferred: `src` is then still to be read and must not be overwritten (in-place act_backward)"""
+        key = fm.t.data_ptr()
+        if not LAZY_IDENTITY or key in self.touched or key in self.pending or src.f32 or fm.f32 or src.C != fm.C:
+            accumulate(self.grad(fm), src)
+            return False
+        self.pending[key] = (fm, src)
+        return True                               # the caller must leave `src` untouched from here on
+
+    def grad_for_write(self, fm: FM):
+        """for a kernel that can overwrite: -> (gradient view of `fm`, accumulate into it?, identity gradient to add as a residual operand or None)"""
+        key = fm.t.data_ptr()
+        if not LAZY_IDENTITY or key in self.touched:
+            return self.grad(fm), True, None
+        p = self.pending.get(key)
+        if p is not None and (p[0].off, p[0].N, p[0].C, p[0].sn) != (fm.off, fm.N, fm.C, fm.sn):
+            return self.grad(fm), True, None      # the waiting identity gradient covers another view of the buffer: add it the plain way
+        self.pending.pop(key, None)
+        self.touched.add(key)
+        return FM(self._mirror(fm.t), fm.off, fm.N, fm.C, fm.sn), False, (p[1] if p is not None else None)
 
     def grad(self, fm: FM) -> FM:
         """the gradient view that mirrors `fm`"""
@@ -171,6 +211,8 @@ class Tape:
         self.deferred.clear()
         self.gbuf.clear()
         self.keep.clear()
+        self.pending.clear()
+        self.touched.clear()
         self.on_node_done = None
         self.touch_log = None
         self.pool = None
@@ -260,16 +302,19 @@ def record_conv(tape: Tape, x: FM, pc, y, act, slope, res, res2, gdn, aux, squar
             yv = ops.from_nchw(nchw_out, Cpad=ops.pad8(pc.cout))
         else:
             g, yv = tape.grad(y), y
+        held = False                              # an identity gradient still to be read from g: the activation derivative goes to a new buffer
         if res is not None and tape.needs_grad(res):
-            accumulate(tape.grad(res), g)
+            held |= tape.add_identity(res, g)
         if res2 is not None and tape.needs_grad(res2):
-            accumulate(tape.grad(res2), g)
+            held |= tape.add_identity(res2, g)
         if g.f32:                                 # fp32 outputs (flow, latents): the MFMA backward kernels take fp16
             g = ops.copy_cast(g, FM.empty(g.N, g.H, g.W, ops.pad8(g.C), device=g.t.device))
+            held = False
+        fresh = (lambda: FM.empty(g.N, g.H, g.W, g.C, dtype=g.t.dtype, device=g.t.device)) if held else (lambda: None)
         if act in (ops.ACT_RELU, ops.ACT_LRELU):
-            g = ops.act_backward(g, yv, act, slope, res=res)
+            g = ops.act_backward(g, yv, act, slope, res=res, out=fresh())
         elif act == ops.ACT_CLAMP01:
-            g = ops.clamp01_backward(g, yv)
+            g = ops.clamp01_backward(g, yv) if not held else ops.clamp01_backward(ops.copy_cast(g, fresh()), yv)
         elif act != ops.ACT_NONE:
             raise NotImplementedError(f"autograd: activation {act}")
         gq = ops.pixel_unshuffle(g) if pc.shuffle else g
@@ -278,7 +323,8 @@ def record_conv(tape: Tape, x: FM, pc, y, act, slope, res, res2, gdn, aux, squar
                                              defer=tape.wbatch),                                     # its reduce stage: batched at join()
                       gq.t, x.t)
         if tape.needs_grad(x):
-            ops.conv_dgrad(pc, gq, tape.grad(x), accumulate=True)
+            gx, acc, extra = tape.grad_for_write(x)
+            ops.conv_dgrad(pc, gq, gx, accumulate=acc, extra=extra)
 
     tape.add(bwd)
 

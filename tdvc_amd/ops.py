@@ -581,12 +581,14 @@ def _dgrad_conv(pc: PackedConv, g_channels: int, x_channels: int) -> PackedConv:
     return pc.dgrad
 
 
-def conv_dgrad(pc: PackedConv, g: FM, dx: FM, accumulate=True) -> FM:
+def conv_dgrad(pc: PackedConv, g: FM, dx: FM, accumulate=True, extra: FM | None = None) -> FM:
     """dX (+)= dL/dx of y = conv(x, W) given g = dL/dy (pre-activation).  Runs on the forward conv kernels with
     the weights packed transposed / mirrored (`convpack.dgrad_tables`); for a sub-pixel layer `g` is the
     un-shuffled gradient (`pixel_unshuffle`), for a stride-2 layer the result is stored through PixelShuffle."""
     dpc = _dgrad_conv(pc, g.C, dx.C)
-    return conv(g, dpc, out=dx, res=dx if accumulate else None)
+    if accumulate:
+        return conv(g, dpc, out=dx, res=dx, res2=extra)
+    return conv(g, dpc, out=dx, res=extra)          # `extra`: one more gradient of the same geometry added in the epilogue (Tape.add_identity)
 
 
 class WgradBatch:

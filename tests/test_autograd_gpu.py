@@ -495,6 +495,16 @@ def test_train_steps_reproducible_with_side_stream_at_training_size(report):
     bad = [k for k in sa if not torch.equal(sa[k], sc[k])]
     report(f"batched against per-layer weight-gradient reduce: {len(bad)}/{len(sa)} state tensors differ after 4 steps")
     assert not bad and prev, f"the batched reduce changes the gradients: {len(bad)} tensors differ, e.g. {bad[:4]}"
+    # round 4: identity gradients of residual connections ride as the next dgrad conv's residual operand (Tape.add_identity) instead of one
+    # add kernel each: the same fp16 sum of the same two values, so the trajectory with the immediate form is bit-identical
+    prev, autograd.LAZY_IDENTITY = autograd.LAZY_IDENTITY, False
+    try:
+        sd, ld = run()
+    finally:
+        autograd.LAZY_IDENTITY = prev
+    bad = [k for k in sa if not torch.equal(sa[k], sd[k])]
+    report(f"lazy against immediate identity gradients: {len(bad)}/{len(sa)} state tensors differ after 4 steps")
+    assert not bad and prev, f"the lazy identity gradients change the result: {len(bad)} tensors differ, e.g. {bad[:4]}"
 
 
 def test_train_step_graph_replay_matches_eager(report):
