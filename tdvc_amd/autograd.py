@@ -335,7 +335,10 @@ def record_scale_act_res(tape: Tape, a: FM, out: FM, gate, act, slope, res, res_
         if out2 is not None:
             accumulate(g, tape.grad(out2))
         if res is not None and tape.needs_grad(res):
-            accumulate(tape.grad(res), g, res_sign)
+            if res_sign == 1.0:
+                tape.add_identity(res, g)                 # (g is not written below: act_backward goes to a fresh buffer)
+            else:
+                accumulate(tape.grad(res), g, res_sign)
         if act in (ops.ACT_RELU, ops.ACT_LRELU):          # y = act(a * gate) + res: the sign of the argument is that of y - res
             g = ops.act_backward(g, out, act, slope, res=res, out=FM.empty(g.N, g.H, g.W, g.C, dtype=g.t.dtype, device=g.t.device))
         elif act != ops.ACT_NONE:
@@ -343,7 +346,7 @@ def record_scale_act_res(tape: Tape, a: FM, out: FM, gate, act, slope, res, res_
         if gate is not None:
             ops.gate_backward(g, a, gate, tape.grad(a) if tape.needs_grad(a) else None, tape.grad_tensor(gate))
         elif tape.needs_grad(a):
-            accumulate(tape.grad(a), g)
+            tape.add_identity(a, g)
 
     tape.add(bwd)
 
@@ -364,7 +367,7 @@ def record_se_gate(tape: Tape, x: FM, p, partial, nblocks, gate):
 def record_clone(tape: Tape, x: FM, out: FM):
     def bwd():
         if tape.needs_grad(x):
-            accumulate(tape.grad(x), tape.grad(out))
+            tape.add_identity(x, tape.grad(out))
 
     tape.add(bwd)
 
