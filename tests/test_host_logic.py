@@ -353,3 +353,43 @@ def test_mirror_pool_carves_zeroed_aligned_mirrors_from_arenas():
     assert loose.shape == nc.shape and len(pool.loose) == 1
     pool.free.setdefault((tuple(x16.shape), x16.dtype, x16.device), []).append(m16)      # what recycle() does after the fills
     assert pool.get(x16) is m16
+
+
+def test_tape_lazy_identity_gradients(monkeypatch):
+    """Tape.add_identity / grad_for_write (host logic, CPU tensors, the add kernel replaced by a recorder): an identity gradient waits for the
+    next writer of the mirror; a dgrad conv that is the first to touch the mirror takes it as its residual operand and overwrites; anything
+    else -- a second writer, a plain grad(), another view of the buffer, an fp32 map -- gets the add the plain way, exactly once"""
+    from tdvc_amd import autograd
+    calls = []
+    monkeypatch.setattr(autograd, "accumulate", lambda dst, src, sign=1.0: calls.append((dst.t.data_ptr(), dst.off, dst.C, src)))
+    h = lambda c=16, dt=torch.float16: ops.FM(torch.zeros(1, 4, 4, c, dtype=dt))
+    tape = autograd.Tape()
+    x, src = h(), h()
+    assert tape.add_identity(x, src) is True and calls == []                 # deferred
+    gx, acc, extra = tape.grad_for_write(x)
+    assert acc is False and extra is src and calls == [] and gx.t.data_ptr() == tape.gbuf[x.t.data_ptr()].data_ptr()
+    _, acc2, extra2 = tape.grad_for_write(x)                                  # a second writer accumulates, nothing waits any more
+    assert acc2 is True and extra2 is None and calls == []
+    assert tape.add_identity(x, src) is False and len(calls) == 1             # the mirror holds a partial sum now: immediate add
+    y = h()
+    assert tape.add_identity(y, src) is True
+    gy = tape.grad(y)                                                         # a plain reader first: the add happens in front of it
+    assert len(calls) == 2 and calls[-1][0] == gy.t.data_ptr() and calls[-1][3] is src
+    z, s16 = h(32), h(16)
+    assert tape.add_identity(z.ch(0, 16), s16) is True
+    _, acc3, extra3 = tape.grad_for_write(z.ch(16, 16))                       # another view of the same buffer: flush, then accumulate
+    assert acc3 is True and extra3 is None and len(calls) == 3 and calls[-1][1:3] == (0, 16)
+    w = h()
+    _, acc4, extra4 = tape.grad_for_write(w)                                  # untouched, nothing waiting: plain overwrite
+    assert acc4 is False and extra4 is None
+    f = h(16, torch.float32)
+    assert tape.add_identity(f, h(16, torch.float32)) is False and len(calls) == 4      # fp32 maps: immediate
+    prev, autograd.LAZY_IDENTITY = autograd.LAZY_IDENTITY, False
+    try:
+        v = h()
+        assert tape.add_identity(v, src) is False and len(calls) == 5
+        assert tape.grad_for_write(h())[1] is True
+    finally:
+        autograd.LAZY_IDENTITY = prev
+    tape.release()
+    assert not tape.pending and not tape.touched
