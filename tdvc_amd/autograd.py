@@ -101,6 +101,7 @@ class Tape:
         # executed after the sweep AND after join(), when no MFMA kernel runs on the side stream any more -- torch's own device code is
         # built WITH packed-FP32 instructions, and its softplus kernels contain the `v_pk_*_f32 ... op_sel:[0,1]` form that returned
         # wrong values next to a concurrent MFMA stream (profiles/r04_torch_packed_fp32_scan.txt)
+        self.fused_aux = False                    # the owner takes the auxiliary loss's gradient from EntropyBottleneck.loss_fused (coder.aux_loss)
         self.touched: set = set()                 # activation buffers whose gradient mirror has been handed out
         self.pending: dict = {}                   # buffer -> (view, identity gradient) not yet added to its mirror (add_identity)
         self.deferred: list = []

@@ -517,11 +517,11 @@ class Cheng2020Anchor(nn.Module, PackCache):
         return x_hat, bits
 
     def aux_loss(self):
-        """compressai `aux_loss()`.  Under this build's tape (training through tdvc_amd.autograd, where nothing carries a torch graph) the
-        value comes from one kernel; `TrainStep` obtains its gradient the same way (EntropyBottleneck.loss_fused).  Outside the tape: the
-        torch expression with its autograd graph, as in compressai."""
+        """compressai `aux_loss()`: the torch expression with its autograd graph over the quantiles (`aux_loss.backward()` works as in
+        tools/train.py:150, also on the value the training-mode forward returns).  Under a tape whose owner takes the gradient from
+        `EntropyBottleneck.loss_fused` instead (`tape.fused_aux`, set by TrainStep) only the value is needed: one kernel."""
         eb = self.entropy_bottleneck
-        if ops.TAPE is not None and eb.quantiles.is_cuda:
+        if ops.TAPE is not None and getattr(ops.TAPE, "fused_aux", False) and eb.quantiles.is_cuda:
             return eb.loss_fused(write_grad=False).reshape(())
         return eb.loss()
 

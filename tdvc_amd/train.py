@@ -236,6 +236,7 @@ class TrainStep:
         self.buckets.zero()
         pool = self._pool if (self.use_pool and self._side is not None and not capturing) else None
         with autograd.record(self.loss_scale, side_stream=self._side, pool=pool) as tape:
+            tape.fused_aux = self._fused                             # the forward's aux_loss() values: no torch graph needed (loss_fused below)
             if self._ready is None:
                 tape.touch_log = {}                                  # first step: learn when each gradient is final
             elif not capturing:
