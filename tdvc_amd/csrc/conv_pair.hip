@@ -12,8 +12,9 @@
 //     of each group: while one waits (LDS latency, a vector-memory instruction being accepted, the pack of a finished row)
 //     the other issues MFMAs.  (A first version with 4 waves holding both weight sets lost a third of its cycles to exactly
 //     those waits: a wave alone on its SIMD pays every one of them.)
-//   * row streaming.  A workgroup walks a strip of 30 output columns top to bottom.  Per step one input row (34 px, by
-//     LDS-DMA into a 16-row ring, 8 rows ahead) enters conv1: its B fragments (16 px x 32 channels) feed the three live
+//   * row streaming.  A workgroup walks a strip of 30 output columns top to bottom (the numbers of this header are the 30-column
+//     geometry's, PairGeo<2>; the 62-column geometry of round 4, PairGeo<4>, is described where it is defined below).  Per step one
+//     input row (34 px, by LDS-DMA into a 16-row ring, 8 rows ahead) enters conv1: its B fragments (16 px x 32 channels) feed the three live
 //     rows of t (dy = 0, 1, 2: three rotating accumulator rows).  The finished row of t (32 px) is written to a small LDS
 //     ring as fp16 -- what the unfused path stores to HBM -- and one step later enters conv2 the same way; the finished
 //     row of y picks up the identity from the input ring, goes through an LDS staging row and leaves as full 128-byte
